@@ -1,0 +1,223 @@
+"""ctypes binding of oracle/libivfpq_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+nothing in the product package (vector_line_quantization_amd/) may import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libivfpq_oracle.so")
+
+
+class _OrcIndex(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("nlist", C.c_int32), ("M", C.c_int32), ("nbits", C.c_int32),
+        ("ksub", C.c_int32), ("dsub", C.c_int32), ("code_size", C.c_int32),
+        ("by_residual", C.c_int32), ("use_precomputed_table", C.c_int32), ("_pad", C.c_int32),
+        ("max_codes", C.c_int64),
+        ("coarse_centroids", C.c_void_p), ("pq_centroids", C.c_void_p),
+        ("precomputed_table", C.c_void_p), ("codes", C.c_void_p), ("ids", C.c_void_p),
+        ("list_offsets", C.c_void_p),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ivfpq_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_fvec_inner_product.restype = C.c_float
+        L.orc_fvec_norm_L2sqr.restype = C.c_float
+        L.orc_fvec_L2sqr.restype = C.c_float
+        L.orc_search_knn_with_key.restype = C.c_int64
+        L.orc_search.restype = C.c_int64
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleIndex:
+    """Plain-data IVFPQ index for the oracle (mirrors the public data members of
+    faiss::IndexIVFPQ, IndexIVFPQ.h:29-47)."""
+
+    def __init__(self, d, nlist, M, nbits, coarse_centroids, pq_centroids,
+                 codes=None, ids=None, list_offsets=None, by_residual=True,
+                 use_precomputed_table=1, max_codes=0, precomputed_table=None):
+        self.d, self.nlist, self.M, self.nbits = d, nlist, M, nbits
+        self.ksub, self.dsub, self.code_size = 1 << nbits, d // M, M
+        self.by_residual = bool(by_residual)
+        self.use_precomputed_table = int(use_precomputed_table)
+        self.max_codes = int(max_codes)
+        self.coarse_centroids = _f32(coarse_centroids).reshape(nlist, d)
+        self.pq_centroids = _f32(pq_centroids).reshape(M, self.ksub, self.dsub)
+        self.set_lists(codes, ids, list_offsets)
+        self.precomputed_table = None if precomputed_table is None else _f32(precomputed_table)
+        if self.precomputed_table is None and self.by_residual and self.use_precomputed_table == 1:
+            self.precomputed_table = self.precompute_table()
+
+    def set_lists(self, codes, ids, list_offsets):
+        if codes is None:
+            codes = np.zeros((0, self.M), np.uint8)
+            ids = np.zeros((0,), np.int64)
+            list_offsets = np.zeros((self.nlist + 1,), np.int64)
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.M)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int64)
+        self.list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+
+    def _c(self):
+        s = _OrcIndex()
+        s.d, s.nlist, s.M, s.nbits = self.d, self.nlist, self.M, self.nbits
+        s.ksub, s.dsub, s.code_size = self.ksub, self.dsub, self.code_size
+        s.by_residual = int(self.by_residual)
+        s.use_precomputed_table = self.use_precomputed_table
+        s.max_codes = self.max_codes
+        s.coarse_centroids = _p(self.coarse_centroids)
+        s.pq_centroids = _p(self.pq_centroids)
+        s.precomputed_table = _p(getattr(self, "precomputed_table", None))
+        s.codes, s.ids, s.list_offsets = _p(self.codes), _p(self.ids), _p(self.list_offsets)
+        return s
+
+    # --- tables -----------------------------------------------------------
+    def precompute_table(self):
+        out = np.empty((self.nlist, self.M, self.ksub), np.float32)
+        s = self._c()
+        lib().orc_precompute_table(C.byref(s), _p(out))
+        return out
+
+    def inner_prod_table(self, x):
+        out = np.empty((self.M, self.ksub), np.float32)
+        s = self._c()
+        lib().orc_compute_inner_prod_table(C.byref(s), _p(_f32(x)), _p(out))
+        return out
+
+    def distance_table(self, x):
+        out = np.empty((self.M, self.ksub), np.float32)
+        s = self._c()
+        lib().orc_compute_distance_table(C.byref(s), _p(_f32(x)), _p(out))
+        return out
+
+    # --- search -----------------------------------------------------------
+    def coarse_search(self, x, nprobe, canonical=False, force_path=0):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        D = np.empty((n, nprobe), np.float32)
+        I = np.empty((n, nprobe), np.int64)
+        lib().orc_knn_L2sqr(_p(x), _p(self.coarse_centroids), C.c_size_t(self.d), C.c_size_t(n),
+                            C.c_size_t(self.nlist), C.c_size_t(nprobe), _p(D), _p(I),
+                            C.c_int(int(canonical)), C.c_int(force_path))
+        return D, I
+
+    def search_preassigned(self, x, keys, coarse_dis, k, store_pairs=False, canonical=False):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(n, -1)
+        coarse_dis = _f32(coarse_dis).reshape(n, -1)
+        nprobe = keys.shape[1]
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        s = self._c()
+        ncode = lib().orc_search_knn_with_key(
+            C.byref(s), C.c_size_t(n), _p(x), _p(keys), _p(coarse_dis), C.c_size_t(nprobe),
+            C.c_size_t(k), _p(D), _p(I), C.c_int(int(store_pairs)), C.c_int(int(canonical)))
+        if ncode < 0:
+            raise ValueError("invalid key")
+        self.last_ncode = int(ncode)
+        return D, I
+
+    def search(self, x, nprobe, k, canonical=False, return_coarse=False):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        keys = np.empty((n, nprobe), np.int64)
+        cdis = np.empty((n, nprobe), np.float32)
+        s = self._c()
+        ncode = lib().orc_search(C.byref(s), C.c_size_t(n), _p(x), C.c_size_t(nprobe),
+                                 C.c_size_t(k), _p(D), _p(I), C.c_int(int(canonical)),
+                                 _p(keys), _p(cdis))
+        self.last_ncode = int(ncode)
+        if return_coarse:
+            return D, I, keys, cdis
+        return D, I
+
+    # --- add --------------------------------------------------------------
+    def encode(self, x, canonical=False):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        assign = np.empty((n,), np.int64)
+        codes = np.empty((n, self.M), np.uint8)
+        s = self._c()
+        lib().orc_encode(C.byref(s), _p(x), C.c_size_t(n), _p(assign), _p(codes),
+                         C.c_int(int(canonical)))
+        return assign, codes
+
+    def add(self, x, xids=None, canonical=False):
+        """IndexIVFPQ::add_core_o (IndexIVFPQ.cpp:192-272): append in input order."""
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        ntotal = self.ids.shape[0]
+        if xids is None:
+            xids = np.arange(ntotal, ntotal + n, dtype=np.int64)
+        assign, codes = self.encode(x, canonical)
+        old_assign = np.repeat(np.arange(self.nlist), np.diff(self.list_offsets))
+        all_assign = np.concatenate([old_assign, assign])
+        all_codes = np.concatenate([self.codes, codes])
+        all_ids = np.concatenate([self.ids, np.asarray(xids, np.int64)])
+        keep = all_assign >= 0
+        order = np.argsort(all_assign[keep], kind="stable")
+        counts = np.bincount(all_assign[keep], minlength=self.nlist)
+        off = np.zeros(self.nlist + 1, np.int64)
+        np.cumsum(counts, out=off[1:])
+        self.set_lists(all_codes[keep][order], all_ids[keep][order], off)
+        return assign, codes
+
+
+def heap_topk(vals, ids, k):
+    vals = _f32(vals)
+    ids = np.ascontiguousarray(ids, np.int64)
+    D = np.empty((k,), np.float32)
+    I = np.empty((k,), np.int64)
+    lib().orc_heap_topk(_p(vals), _p(ids), C.c_size_t(vals.shape[0]), C.c_size_t(k), _p(D), _p(I))
+    return D, I
+
+
+def fvec_inner_product(x, y):
+    x, y = _f32(x), _f32(y)
+    return lib().orc_fvec_inner_product(_p(x), _p(y), C.c_size_t(x.shape[0]))
+
+
+def fvec_L2sqr(x, y):
+    x, y = _f32(x), _f32(y)
+    return lib().orc_fvec_L2sqr(_p(x), _p(y), C.c_size_t(x.shape[0]))
+
+
+def fvec_norm_L2sqr(x):
+    x = _f32(x)
+    return lib().orc_fvec_norm_L2sqr(_p(x), C.c_size_t(x.shape[0]))
+
+
+def num_threads():
+    return lib().orc_num_threads()
