@@ -1,0 +1,134 @@
+/*
+ * vlq_ivfpq.h -- C ABI of the MI355X-native IVF(PQ) list-scan search path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference tree).  The C++ shell that mirrors faiss::Index / IndexIVFPQ /
+ * gpu::GpuIndexIVFPQ on top of these calls is include/faiss_amd/ ; the binding a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions (Index.h:25-36, :62): vectors are row-major float32 x[i*d+j];
+ * labels are int64; results are ascending squared-L2 distances; missing results
+ * are label -1 / distance FLT_MAX (Heap.h:76-78,318-321).
+ *
+ * Pointers marked [h|d] may be host or device memory (the reference accepts
+ * either, gpu/utils/CopyUtils.cuh); device pointers must belong to the index's
+ * device.  All work is issued on the index's stream (vlq_ivfpq_set_stream); calls
+ * with host output buffers return after the results have landed, calls whose
+ * buffers are all device-resident are asynchronous on that stream.
+ *
+ * Every function returns VLQ_OK or an error code; vlq_last_error() gives the
+ * message of the last failure on the calling thread.  There is no CPU fallback:
+ * without a HIP device every compute entry point fails with VLQ_ERR_HIP.
+ */
+#ifndef VLQ_IVFPQ_H
+#define VLQ_IVFPQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vlq_ivfpq_s* vlq_ivfpq_t;
+
+enum {
+    VLQ_OK = 0,
+    VLQ_ERR_INVALID = 1,      /* bad argument (FAISS_THROW_* in the reference)      */
+    VLQ_ERR_HIP = 2,          /* HIP runtime failure (CUDA_VERIFY in the reference) */
+    VLQ_ERR_UNSUPPORTED = 3,  /* outside the implemented envelope                   */
+    VLQ_ERR_STATE = 4         /* index not trained / lists not loaded               */
+};
+
+#define VLQ_MAX_K 1024        /* gpu/impl/IVFPQ.cu:966-967 */
+#define VLQ_MAX_NPROBE 1024
+
+int vlq_version(void);
+const char* vlq_last_error(void);
+/* number of HIP devices visible (0 if none / no driver) */
+int vlq_device_count(void);
+
+/* GpuIndexIVFPQ(resources, dims, nlist, subQuantizers, bitsPerCode, METRIC_L2, cfg)
+ * gpu/GpuIndexIVFPQ.h:52-58 ; IndexIVFPQ(quantizer, d, nlist, M, nbits) IndexIVFPQ.h:49-51.
+ * Requires d % M == 0, 1 <= nbits <= 8 (IndexIVFPQ.cpp:51). */
+int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int nbits);
+void vlq_ivfpq_destroy(vlq_ivfpq_t h);
+
+/* GpuResources::getDefaultStream (gpu/GpuResources.h:36): run on the caller's
+ * hipStream_t (NULL = the index's own stream). */
+int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream);
+
+/* GpuIndexIVF::copyFrom: coarse centroids = IndexFlatL2::xb of the quantizer
+ * (gpu/GpuIndexIVF.cu:120-150).  centroids: [nlist*d] [h|d]. */
+int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids);
+
+/* ProductQuantizer::centroids [M][ksub][dsub] (ProductQuantizer.h:51-60),
+ * GpuIndexIVFPQ::copyFrom gpu/GpuIndexIVFPQ.cu:168-231. [h|d] */
+int vlq_ivfpq_set_pq_centroids(vlq_ivfpq_t h, const float* centroids);
+
+/* IndexIVFPQ public search-time fields (IndexIVFPQ.h:30-41):
+ * by_residual, use_precomputed_table (0 or 1; 1 builds the table on the device,
+ * = IndexIVFPQ::precompute_table IndexIVFPQ.cpp:392-429), max_codes (0 = off). */
+int vlq_ivfpq_set_search_options(vlq_ivfpq_t h, int by_residual, int use_precomputed_table,
+                                 int64_t max_codes);
+
+/* Bulk load of the inverted lists (copyFrom of IndexIVF::ids / IndexIVFPQ::codes,
+ * IndexIVF.h:55, IndexIVFPQ.h:43) in list-contiguous form:
+ *   codes[ntotal][M] u8, ids[ntotal] i64, list_offsets[nlist+1] i64.  [h|d] */
+int vlq_ivfpq_set_lists(vlq_ivfpq_t h, const uint8_t* codes, const int64_t* ids,
+                        const int64_t* list_offsets);
+
+/* IndexIVFPQ::add_with_ids (IndexIVFPQ.cpp:186-272) on the device: coarse 1-NN,
+ * residual, per-sub-quantizer argmin (first minimum wins), append in input order.
+ * xids may be NULL (ids ntotal..ntotal+n-1).  x [h|d], xids [h|d]. */
+int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids);
+
+/* Encode only: assign[n] i64 and codes[n][M] u8 (IndexIVFPQ::encode_multiple with
+ * compute_keys=true, IndexIVFPQ.cpp:150-167).  Outputs [h|d]. */
+int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes);
+
+int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h);
+/* GpuIndexIVFPQ::getListLength / getListCodes / getListIndices
+ * (gpu/GpuIndexIVFPQ.h:120-131).  codes_out/ids_out are host buffers. */
+int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len);
+int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* ids_out);
+
+/* IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) = GpuIndexIVFPQ::search.
+ * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024. */
+int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k,
+                     float* D, int64_t* I);
+
+/* The parity seam: IndexIVFPQ::search_knn_with_key (IndexIVFPQ.h:140-146,
+ * IndexIVFPQ.cpp:964-1060).  keys[n*nprobe] (-1 = skip), coarse_dis[n*nprobe].
+ * store_pairs != 0 returns list<<32|offset as label.  All buffers [h|d]. */
+int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* keys,
+                                 const float* coarse_dis, int nprobe, int k, float* D,
+                                 int64_t* I, int store_pairs);
+
+/* quantizer->search (IndexIVFPQ.cpp:1073 -> IndexFlat.cpp:42-56): top-nprobe
+ * coarse centroids, ascending.  Outputs [h|d]. */
+int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe,
+                            float* coarse_dis, int64_t* keys);
+
+/* Introspection for parity tests (host output buffers):
+ *   query tables  = ProductQuantizer::compute_inner_prod_table /
+ *                   compute_distance_table (ProductQuantizer.cpp:410-436): out[n][M][ksub]
+ *   precomputed   = IndexIVFPQ::precomputed_table [nlist][M][ksub]               */
+int vlq_ivfpq_query_tables(vlq_ivfpq_t h, int64_t n, const float* x, int inner_product, float* out);
+int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out);
+
+/* indexIVFPQ_stats (IndexIVFPQ.h:169-195): codes visited since the last reset. */
+int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset);
+
+/* HIP-event timing of the stages of the search calls issued since the last
+ * reset, on the index's stream: ms[0]=coarse (norms+GEMM+select), ms[1]=query
+ * tables, ms[2]=list scan (+top-k), calls = number of timed scan launches.
+ * enable != 0 switches event recording on. */
+int vlq_ivfpq_profile(vlq_ivfpq_t h, int enable);
+int vlq_ivfpq_profile_read(vlq_ivfpq_t h, double ms[3], int64_t* calls, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLQ_IVFPQ_H */

@@ -1,0 +1,184 @@
+"""GPU parity (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI, against the oracle restatement and the committed reference fixtures."""
+import numpy as np
+import pytest
+
+import vector_line_quantization_amd as vlq
+from oracle import pyoracle
+from util import CASE_NAMES, Case, assert_same_topk, bits, sha
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_index(case, with_lists=True):
+    g = vlq.GpuIVFPQ(case.d, case.nlist, case.M, case.nbits)
+    g.set_coarse_centroids(case["coarse_centroids"])
+    g.set_pq_centroids(case["pq_centroids"])
+    g.set_search_options(by_residual=case.by_residual, use_precomputed_table=case.mode,
+                         max_codes=case.max_codes)
+    if with_lists:
+        g.set_lists(case["codes"], case["ids"], case["list_offsets"])
+    return g
+
+
+@pytest.fixture(scope="module", params=CASE_NAMES)
+def case(request):
+    return Case(request.param)
+
+
+def test_query_tables_bit_exact(case):
+    g = gpu_index(case)
+    n = min(8, case.nq)
+    ip = g.query_tables(case.xq[:n], inner_product=True)
+    dt = g.query_tables(case.xq[:n], inner_product=False)
+    assert np.array_equal(bits(ip[:2]), bits(case["ip_table_head"]))
+    assert np.array_equal(sha(ip), case["ip_table_sha256"])
+    assert np.array_equal(bits(dt[:2]), bits(case["dis_table_head"]))
+    assert np.array_equal(sha(dt), case["dis_table_sha256"])
+
+
+def test_precomputed_table_bit_exact(case):
+    if case.mode != 1:
+        pytest.skip("no precomputed table in this mode")
+    g = gpu_index(case)
+    t = g.precomputed_table()
+    assert np.array_equal(bits(t[:3]), bits(case["precomputed_table_head"]))
+    assert np.array_equal(sha(t), case["precomputed_table_sha256"])
+
+
+def test_scan_seam_vs_reference_and_oracle(case):
+    """search_knn_with_key with the reference's own (keys, coarse_dis)."""
+    g = gpu_index(case)
+    D, I = g.search_preassigned(case.xq, case["keys"], case["coarse_dis"], case.k)
+    # reference: distances bit-exact, labels modulo exact-distance ties
+    assert_same_topk(D, I, case["D"], case["I"], case.name)
+    # oracle in canonical (distance, scan position) order: everything identical
+    ox = case.oracle_index()
+    Do, Io = ox.search_preassigned(case.xq, case["keys"], case["coarse_dis"], case.k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    nq, ncode = g.stats(reset=True)
+    assert ncode == int(case["ncode"][0]) and nq == case.nq
+    Dp, Ip = g.search_preassigned(case.xq, case["keys"], case["coarse_dis"], case.k, store_pairs=True)
+    assert_same_topk(Dp, Ip, case["D_pairs"], case["I_pairs"], case.name + " pairs")
+
+
+def test_coarse_bit_exact_vs_oracle(case):
+    g = gpu_index(case)
+    ox = case.oracle_index()
+    cd, keys = g.coarse_search(case.xq, case.nprobe)
+    cdo, keyso = ox.coarse_search(case.xq, case.nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+    # and against the reference (BLAS summation order unpinned): to rounding
+    same = keys == case["keys"]
+    assert same.mean() >= 0.999
+    ref = case["coarse_dis"]
+    rel = np.abs(cd[same] - ref[same]) / np.maximum(np.abs(ref[same]), 1e-20)
+    assert rel.max() <= 1e-5
+
+
+def test_coarse_small_batch_matches_reference(case):
+    """< 20 queries: the reference takes the SSE path (no BLAS) -> bit-exact."""
+    if case.n_small == 0:
+        pytest.skip("no small batch in this fixture")
+    g = gpu_index(case)
+    cd, keys = g.coarse_search(case.xq[:case.n_small], case.nprobe)
+    assert_same_topk(cd, keys, case["small_coarse_dis"], case["small_keys"], case.name)
+    D, I = g.search(case.xq[:case.n_small], case.nprobe, case.k)
+    assert_same_topk(D, I, case["small_D"], case["small_I"], case.name)
+
+
+def test_full_search_vs_oracle_and_reference(case):
+    g = gpu_index(case)
+    ox = case.oracle_index()
+    D, I = g.search(case.xq, case.nprobe, case.k)
+    Do, Io = ox.search(case.xq, case.nprobe, case.k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    Dr, Ir = case["D"], case["I"]
+    same = I == Ir
+    assert same.mean() >= 0.99
+    m = same & (Ir >= 0)
+    rel = np.abs(D[m] - Dr[m]) / np.maximum(np.abs(Dr[m]), 1e-20)
+    assert rel.max() <= 1e-4      # north-star tolerance on distances
+
+
+def test_encode_and_add(case):
+    g = gpu_index(case, with_lists=False)
+    ox = case.oracle_index(with_lists=False)
+    assign, codes = g.encode(case.xb)
+    ao, co = ox.encode(case.xb, canonical=True)
+    assert np.array_equal(assign, ao)
+    assert np.array_equal(codes, co)
+    g.add(case.xb, case.xids)
+    ox.add(case.xb, case.xids, canonical=True)
+    for i in range(case.nlist):
+        c, ids = g.get_list(i)
+        o0, o1 = ox.list_offsets[i], ox.list_offsets[i + 1]
+        assert np.array_equal(ids, ox.ids[o0:o1])
+        assert np.array_equal(c, ox.codes[o0:o1])
+    agree = assign == case["xb_assign"]
+    assert agree.mean() >= 0.999
+    if agree.all():   # then the lists equal the reference's byte for byte
+        off = case["list_offsets"]
+        for i in range(case.nlist):
+            c, ids = g.get_list(i)
+            assert np.array_equal(ids, case["ids"][off[i]:off[i + 1]])
+            assert np.array_equal(c, case["codes"][off[i]:off[i + 1]])
+
+
+@pytest.mark.parametrize("k", [1, 64, 65, 256, 257, 1024])
+def test_large_k_and_k_boundaries(k):
+    """k at the edges of the per-lane key counts of the wave select (1/4/16)."""
+    case = Case("deep_like_dsub6")
+    g = gpu_index(case)
+    ox = case.oracle_index()
+    D, I = g.search_preassigned(case.xq, case["keys"], case["coarse_dis"], k)
+    Do, Io = ox.search_preassigned(case.xq, case["keys"], case["coarse_dis"], k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+
+
+@pytest.mark.parametrize("nprobe", [1, 37, 64, 65, 300])
+def test_nprobe_edges(nprobe):
+    """nprobe above nlist pads the coarse result with -1 keys which the scan skips."""
+    case = Case("c1_small")
+    g = gpu_index(case)
+    ox = case.oracle_index()
+    D, I = g.search(case.xq, nprobe, 10)
+    Do, Io = ox.search(case.xq, nprobe, 10, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+
+
+def test_empty_and_error_paths():
+    case = Case("tiny_padding")
+    g = gpu_index(case, with_lists=False)
+    D, I = g.search(case.xq, 4, 5)                      # empty index: all padding
+    assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
+    D, I = g.search(case.xq[:0], 4, 5)                  # empty batch
+    assert D.shape == (0, 5)
+    with pytest.raises(vlq.VlqError):
+        g.search(case.xq, 0, 5)
+    with pytest.raises(vlq.VlqError):
+        g.search(case.xq, 4, 2000)
+    bad = np.full((case.nq, 2), case.nlist + 3, np.int64)
+    g.search_preassigned(case.xq, bad, np.zeros((case.nq, 2), np.float32), 3)
+    with pytest.raises(vlq.VlqError):                    # reference: "Invalid key" + throw
+        g.stats()
+
+
+def test_device_resident_buffers():
+    """Inputs and outputs already in HBM (torch tensors as plain device memory)."""
+    import torch
+    case = Case("c1_small")
+    g = gpu_index(case)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    xq = torch.from_numpy(case.xq).cuda()
+    D, I = g.search(xq, case.nprobe, case.k)
+    torch.cuda.synchronize()
+    ox = case.oracle_index()
+    Do, Io = ox.search(case.xq, case.nprobe, case.k, canonical=True)
+    assert np.array_equal(bits(D.cpu().numpy()), bits(Do))
+    assert np.array_equal(I.cpu().numpy(), Io)

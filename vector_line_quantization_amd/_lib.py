@@ -1,0 +1,63 @@
+"""ctypes loader of csrc/libvlq_ivfpq.so (the C ABI of include/vlq_ivfpq.h)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libvlq_ivfpq.so")
+
+# every symbol include/vlq_ivfpq.h declares
+SYMBOLS = [
+    "vlq_version", "vlq_last_error", "vlq_device_count", "vlq_ivfpq_create", "vlq_ivfpq_destroy",
+    "vlq_ivfpq_set_stream", "vlq_ivfpq_set_coarse_centroids", "vlq_ivfpq_set_pq_centroids",
+    "vlq_ivfpq_set_search_options", "vlq_ivfpq_set_lists", "vlq_ivfpq_add", "vlq_ivfpq_encode",
+    "vlq_ivfpq_ntotal", "vlq_ivfpq_list_length", "vlq_ivfpq_get_list", "vlq_ivfpq_search",
+    "vlq_ivfpq_search_preassigned", "vlq_ivfpq_coarse_search", "vlq_ivfpq_query_tables",
+    "vlq_ivfpq_get_precomputed_table", "vlq_ivfpq_stats", "vlq_ivfpq_profile",
+    "vlq_ivfpq_profile_read",
+]
+
+
+class VlqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vlq error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU present."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _CSRC])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise VlqError(-1, "HIP library %s is not built (run `make -C %s`); there is no "
+                               "fallback path" % (_SO, _CSRC))
+        L = C.CDLL(_SO)
+        L.vlq_last_error.restype = C.c_char_p
+        L.vlq_ivfpq_ntotal.restype = C.c_int64
+        L.vlq_ivfpq_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VlqError(rc, lib().vlq_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return lib().vlq_device_count()

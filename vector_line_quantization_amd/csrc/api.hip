@@ -1,0 +1,666 @@
+// C ABI (include/vlq_ivfpq.h) over the HIP kernels.  Host-side orchestration only:
+// device buffers, workspace, paging of large query batches, host<->device staging.
+// No CPU compute path exists here: every search/add entry point launches kernels.
+#include "../../include/vlq_ivfpq.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(VLQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != VLQ_OK) return rc_; \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return VLQ_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e != hipSuccess) { p = nullptr; return fail(VLQ_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = want;
+        return VLQ_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+}  // namespace
+
+struct vlq_ivfpq_s {
+    int device = 0, d = 0, nlist = 0, M = 0, nbits = 0, ksub = 0, dsub = 0;
+    int by_residual = 1, use_precomputed_table = 1;
+    int64_t max_codes = 0;
+    int64_t ntotal = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    DevBuf coarse, cnorm, pq, rnorm, term2, codes, ids, list_off;
+    bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
+    std::vector<int64_t> h_list_off;
+
+    // workspace
+    DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
+        ws_cdis_in, ws_codes, ws_assign;
+    DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
+    uint64_t stat_nq = 0;
+
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    struct Pending { hipEvent_t a, b; int stage; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_calls = 0;
+};
+
+namespace {
+
+int set_dev(vlq_ivfpq_t h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return VLQ_OK;
+}
+
+// stage an input: returns a device pointer holding `bytes` of src
+int stage_in(vlq_ivfpq_t h, const void* src, size_t bytes, DevBuf& ws, const void** out) {
+    if (bytes == 0) { *out = src; return VLQ_OK; }
+    if (is_device_ptr(src)) { *out = src; return VLQ_OK; }
+    TRY(ws.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(ws.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = ws.p;
+    return VLQ_OK;
+}
+
+// pick the device-side destination of an output
+int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy) {
+    if (is_device_ptr(dst)) { *dev = dst; *need_copy = false; return VLQ_OK; }
+    TRY(ws.reserve(bytes));
+    *dev = ws.p;
+    *need_copy = true;
+    return VLQ_OK;
+}
+
+hipEvent_t get_event(vlq_ivfpq_t h) {
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct StageTimer {
+    vlq_ivfpq_t h; int stage; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(vlq_ivfpq_t h_, int stage_) : h(h_), stage(stage_) {
+        if (!h->prof) return;
+        a = get_event(h); b = get_event(h);
+        if (a) (void)hipEventRecord(a, h->stream);
+    }
+    void stop() {
+        if (!h->prof || !a || !b) return;
+        (void)hipEventRecord(b, h->stream);
+        h->pending.push_back({a, b, stage});
+        a = b = nullptr;
+    }
+};
+
+void drain_profile(vlq_ivfpq_t h) {
+    for (auto& p : h->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->prof_ms[p.stage] += ms;
+            if (p.stage == 2) h->prof_calls++;
+        }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+int ensure_term2(vlq_ivfpq_t h) {
+    if (!(h->by_residual && h->use_precomputed_table == 1)) return VLQ_OK;
+    if (h->term2_valid) return VLQ_OK;
+    if (!h->have_coarse || !h->have_pq) return fail(VLQ_ERR_STATE, "centroids not set");
+    const size_t E = (size_t)h->M * h->ksub;
+    TRY(h->term2.reserve((size_t)h->nlist * E * sizeof(float)));
+    // IndexIVFPQ::precompute_table (IndexIVFPQ.cpp:411-429)
+    vlq::launch_pq_tables(h->coarse.as<float>(), h->nlist, h->d, h->pq.as<float>(), h->M, h->ksub,
+                          h->dsub, h->rnorm.as<float>(), 2, h->term2.as<float>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    h->term2_valid = true;
+    return VLQ_OK;
+}
+
+int check_ready(vlq_ivfpq_t h, bool need_lists) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (!h->have_coarse) return fail(VLQ_ERR_STATE, "coarse centroids not set (index not trained)");
+    if (!h->have_pq) return fail(VLQ_ERR_STATE, "PQ centroids not set (index not trained)");
+    if (need_lists && !h->have_lists) return fail(VLQ_ERR_STATE, "inverted lists not loaded");
+    return VLQ_OK;
+}
+
+int64_t query_page(vlq_ivfpq_t h) {
+    // GpuIndex::search pages at 32768 queries (gpu/GpuIndex.cu:29,108-147); also keep the
+    // [page][nlist] distance matrix under 1 GiB
+    int64_t page = 32768;
+    int64_t by_mat = (int64_t)((size_t(1) << 28) / (size_t)std::max(1, h->nlist));
+    page = std::max<int64_t>(1, std::min(page, by_mat));
+    return page;
+}
+
+// coarse stage on device buffers: x_dev [n][d] -> cdis_dev, keys_dev [n][nprobe]
+int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
+               int64_t* keys_dev) {
+    StageTimer tm(h, 0);
+    const int64_t page = query_page(h);
+    // knn_L2sqr dispatch (utils.cpp:935-946): small batches bypass the GEMM formulation
+    const bool direct = (h->d % 4 == 0) && n < 20;
+    TRY(h->ws_qn.reserve((size_t)std::min(n, page) * sizeof(float)));
+    TRY(h->ws_dist.reserve((size_t)std::min(n, page) * h->nlist * sizeof(float)));
+    for (int64_t i0 = 0; i0 < n; i0 += page) {
+        const int64_t ni = std::min(page, n - i0);
+        const float* xi = x_dev + i0 * h->d;
+        if (direct) {
+            vlq::launch_coarse_distances_direct(xi, h->coarse.as<float>(), h->ws_dist.as<float>(),
+                                                ni, h->nlist, h->d, h->stream);
+        } else {
+            vlq::launch_row_norms(xi, ni, h->d, h->ws_qn.as<float>(), h->stream);
+            vlq::launch_coarse_distances(xi, h->coarse.as<float>(), h->ws_qn.as<float>(),
+                                         h->cnorm.as<float>(), h->ws_dist.as<float>(), ni,
+                                         h->nlist, h->d, h->stream);
+        }
+        vlq::launch_coarse_select(h->ws_dist.as<float>(), ni, h->nlist, nprobe,
+                                  cdis_dev + i0 * nprobe, keys_dev + i0 * nprobe, h->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    tm.stop();
+    return VLQ_OK;
+}
+
+int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_dev,
+             const float* cdis_dev, int nprobe, int k, float* D_dev, int64_t* I_dev,
+             int store_pairs) {
+    TRY(ensure_term2(h));
+    const size_t E = (size_t)h->M * h->ksub;
+    const int table_mode = !h->by_residual ? 2 : (h->use_precomputed_table == 1 ? 1 : 0);
+    const int64_t page = 32768;
+    if (table_mode != 0) TRY(h->ws_qtab.reserve((size_t)std::min(n, page) * E * sizeof(float)));
+    for (int64_t i0 = 0; i0 < n; i0 += page) {
+        const int64_t ni = std::min(page, n - i0);
+        const float* xi = x_dev + i0 * h->d;
+        if (table_mode != 0) {
+            StageTimer tm(h, 1);
+            // init_query_L2 (IndexIVFPQ.cpp:557-563): ip table (mode 1) or distance table
+            vlq::launch_pq_tables(xi, ni, h->d, h->pq.as<float>(), h->M, h->ksub, h->dsub, nullptr,
+                                  table_mode == 1 ? 0 : 1, h->ws_qtab.as<float>(), h->stream);
+            tm.stop();
+        }
+        StageTimer tm(h, 2);
+        vlq::ScanArgs a;
+        a.codes = h->codes.as<uint8_t>();
+        a.ids = h->ids.as<int64_t>();
+        a.list_off = h->list_off.as<int64_t>();
+        a.term2 = table_mode == 1 ? h->term2.as<float>() : nullptr;
+        a.qtab = table_mode != 0 ? h->ws_qtab.as<float>() : nullptr;
+        a.queries = xi;
+        a.coarse = h->coarse.as<float>();
+        a.pq_cent = h->pq.as<float>();
+        a.keys = keys_dev + i0 * nprobe;
+        a.coarse_dis = cdis_dev + i0 * nprobe;
+        a.D = D_dev + i0 * k;
+        a.I = I_dev + i0 * k;
+        a.ncode = h->stats.as<unsigned long long>();
+        a.bad_key = reinterpret_cast<int*>(h->stats.as<unsigned long long>() + 1);
+        a.nq = ni;
+        a.nprobe = nprobe; a.k = k; a.M = h->M; a.ksub = h->ksub; a.dsub = h->dsub; a.d = h->d;
+        a.nlist = h->nlist;
+        a.table_mode = table_mode;
+        a.max_codes = h->max_codes;
+        a.store_pairs = store_pairs;
+        vlq::launch_scan(a, h->stream);
+        tm.stop();
+    }
+    HIP_TRY(hipGetLastError());
+    h->stat_nq += (uint64_t)n;
+    return VLQ_OK;
+}
+
+int check_search_args(vlq_ivfpq_t h, int64_t n, const void* x, int nprobe, int k, const void* D,
+                      const void* I) {
+    if (n < 0) return fail(VLQ_ERR_INVALID, "n < 0");
+    if (n > 0 && (!x || !D || !I)) return fail(VLQ_ERR_INVALID, "null buffer");
+    if (nprobe < 1 || nprobe > VLQ_MAX_NPROBE)
+        return fail(VLQ_ERR_INVALID, "nprobe=%d outside 1..%d", nprobe, VLQ_MAX_NPROBE);
+    if (k < 1 || k > VLQ_MAX_K) return fail(VLQ_ERR_INVALID, "k=%d outside 1..%d", k, VLQ_MAX_K);
+    (void)h;
+    return VLQ_OK;
+}
+
+int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t bytesD, bool copyI,
+                   void* I, const void* Id, size_t bytesI) {
+    if (copyD) HIP_TRY(hipMemcpyAsync(D, Dd, bytesD, hipMemcpyDeviceToHost, h->stream));
+    if (copyI) HIP_TRY(hipMemcpyAsync(I, Id, bytesI, hipMemcpyDeviceToHost, h->stream));
+    if (copyD || copyI) HIP_TRY(hipStreamSynchronize(h->stream));
+    return VLQ_OK;
+}
+
+int read_bad_key(vlq_ivfpq_t h) {
+    // only meaningful after a synchronisation; checked lazily in vlq_ivfpq_stats
+    (void)h;
+    return VLQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlq_version(void) { return 100; }
+
+const char* vlq_last_error(void) { return g_err.c_str(); }
+
+int vlq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int nbits) {
+    if (!out) return fail(VLQ_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (d <= 0 || nlist <= 0 || M <= 0) return fail(VLQ_ERR_INVALID, "d, nlist, M must be positive");
+    if (d % M != 0) return fail(VLQ_ERR_INVALID, "d=%d not a multiple of M=%d", d, M);   // ProductQuantizer.cpp:165
+    if (nbits < 1 || nbits > 8) return fail(VLQ_ERR_INVALID, "nbits=%d outside 1..8", nbits);  // IndexIVFPQ.cpp:51
+    if ((size_t)M * (size_t)(1 << nbits) * 4 > 144 * 1024)
+        return fail(VLQ_ERR_UNSUPPORTED, "M * 2^nbits lookup table exceeds the LDS budget");
+    int ndev = vlq_device_count();
+    if (ndev <= 0) return fail(VLQ_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VLQ_ERR_INVALID, "device %d out of range", device);
+    vlq_ivfpq_s* h = new (std::nothrow) vlq_ivfpq_s();
+    if (!h) return fail(VLQ_ERR_INVALID, "out of memory");
+    h->device = device; h->d = d; h->nlist = nlist; h->M = M; h->nbits = nbits;
+    h->ksub = 1 << nbits; h->dsub = d / M;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    h->h_list_off.assign((size_t)nlist + 1, 0);
+    int rc = h->stats.reserve(16);
+    if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
+    if (rc == VLQ_OK) rc = h->codes.reserve(16);
+    if (rc == VLQ_OK) rc = h->ids.reserve(16);
+    if (rc != VLQ_OK) { vlq_ivfpq_destroy(h); return rc; }
+    (void)hipMemsetAsync(h->stats.p, 0, 16, h->stream);
+    (void)hipMemsetAsync(h->list_off.p, 0, ((size_t)nlist + 1) * 8, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    h->have_lists = true;   // an empty index is searchable (all lists empty)
+    *out = h;
+    return VLQ_OK;
+}
+
+void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    drain_profile(h);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->rnorm, &h->term2, &h->codes, &h->ids,
+                      &h->list_off, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
+                      &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
+                      &h->ws_codes, &h->ws_assign, &h->stats};
+    for (auto b : bufs) b->release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
+    if (!h || !centroids) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h));
+    const size_t bytes = (size_t)h->nlist * h->d * sizeof(float);
+    TRY(h->coarse.reserve(bytes));
+    TRY(h->cnorm.reserve((size_t)h->nlist * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(h->coarse.p, centroids, bytes, hipMemcpyDefault, h->stream));
+    // y_norms of knn_L2sqr_blas (utils.cpp:857-858), computed once
+    vlq::launch_row_norms(h->coarse.as<float>(), h->nlist, h->d, h->cnorm.as<float>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_coarse = true;
+    h->term2_valid = false;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_pq_centroids(vlq_ivfpq_t h, const float* centroids) {
+    if (!h || !centroids) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h));
+    const size_t n = (size_t)h->M * h->ksub;
+    const size_t bytes = n * h->dsub * sizeof(float);
+    TRY(h->pq.reserve(bytes));
+    TRY(h->rnorm.reserve(n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(h->pq.p, centroids, bytes, hipMemcpyDefault, h->stream));
+    // r_norms (IndexIVFPQ.cpp:411-416)
+    vlq::launch_row_norms(h->pq.as<float>(), (int64_t)n, h->dsub, h->rnorm.as<float>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_pq = true;
+    h->term2_valid = false;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_search_options(vlq_ivfpq_t h, int by_residual, int use_precomputed_table,
+                                 int64_t max_codes) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (use_precomputed_table != 0 && use_precomputed_table != 1)
+        return fail(VLQ_ERR_UNSUPPORTED, "use_precomputed_table=%d (only 0 and 1; 2 = IMI not built)",
+                    use_precomputed_table);
+    if (max_codes < 0) return fail(VLQ_ERR_INVALID, "max_codes < 0");
+    h->by_residual = by_residual ? 1 : 0;
+    h->use_precomputed_table = use_precomputed_table;
+    h->max_codes = max_codes;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_lists(vlq_ivfpq_t h, const uint8_t* codes, const int64_t* ids,
+                        const int64_t* list_offsets) {
+    if (!h || !list_offsets) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h));
+    std::vector<int64_t> off((size_t)h->nlist + 1);
+    HIP_TRY(hipMemcpy(off.data(), list_offsets, off.size() * 8, hipMemcpyDefault));
+    if (off[0] != 0) return fail(VLQ_ERR_INVALID, "list_offsets[0] != 0");
+    for (int i = 0; i < h->nlist; i++) {
+        if (off[i + 1] < off[i]) return fail(VLQ_ERR_INVALID, "list_offsets not monotone at %d", i);
+        if (off[i + 1] - off[i] >= (int64_t(1) << 31))
+            return fail(VLQ_ERR_UNSUPPORTED, "list %d longer than 2^31", i);
+    }
+    const int64_t ntotal = off[h->nlist];
+    if (ntotal > 0 && (!codes || !ids)) return fail(VLQ_ERR_INVALID, "null codes/ids");
+    TRY(h->codes.reserve((size_t)ntotal * h->M + 16));
+    TRY(h->ids.reserve((size_t)ntotal * 8 + 16));
+    if (ntotal > 0) {
+        HIP_TRY(hipMemcpyAsync(h->codes.p, codes, (size_t)ntotal * h->M, hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->ids.p, ids, (size_t)ntotal * 8, hipMemcpyDefault, h->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(h->list_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->h_list_off = off;
+    h->ntotal = ntotal;
+    h->have_lists = true;
+    return VLQ_OK;
+}
+
+int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h) { return h ? h->ntotal : -1; }
+
+int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len) {
+    if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
+    if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
+    *len = h->h_list_off[list_id + 1] - h->h_list_off[list_id];
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* ids_out) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
+    TRY(set_dev(h));
+    const int64_t o = h->h_list_off[list_id], len = h->h_list_off[list_id + 1] - o;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (len > 0 && codes_out)
+        HIP_TRY(hipMemcpy(codes_out, h->codes.as<uint8_t>() + o * h->M, (size_t)len * h->M, hipMemcpyDeviceToHost));
+    if (len > 0 && ids_out)
+        HIP_TRY(hipMemcpy(ids_out, h->ids.as<int64_t>() + o, (size_t)len * 8, hipMemcpyDeviceToHost));
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe,
+                            float* coarse_dis, int64_t* keys) {
+    TRY(check_ready(h, false));
+    TRY(check_search_args(h, n, x, nprobe, 1, coarse_dis, keys));
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const void* xd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    void *cd, *kd;
+    bool copy_c, copy_k;
+    TRY(stage_out(coarse_dis, (size_t)n * nprobe * 4, h->ws_cdis, &cd, &copy_c));
+    TRY(stage_out(keys, (size_t)n * nprobe * 8, h->ws_keys, &kd, &copy_k));
+    TRY(coarse_dev(h, n, (const float*)xd, nprobe, (float*)cd, (int64_t*)kd));
+    return finish_outputs(h, copy_c, coarse_dis, cd, (size_t)n * nprobe * 4, copy_k, keys, kd,
+                          (size_t)n * nprobe * 8);
+}
+
+int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* keys,
+                                 const float* coarse_dis, int nprobe, int k, float* D, int64_t* I,
+                                 int store_pairs) {
+    TRY(check_ready(h, true));
+    TRY(check_search_args(h, n, x, nprobe, k, D, I));
+    if (n > 0 && (!keys || !coarse_dis)) return fail(VLQ_ERR_INVALID, "null keys/coarse_dis");
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const void *xd, *kd, *cd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    TRY(stage_in(h, keys, (size_t)n * nprobe * 8, h->ws_keys_in, &kd));
+    TRY(stage_in(h, coarse_dis, (size_t)n * nprobe * 4, h->ws_cdis_in, &cd));
+    void *Dd, *Id;
+    bool copyD, copyI;
+    TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
+    TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
+    TRY(scan_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k,
+                 (float*)Dd, (int64_t*)Id, store_pairs));
+    return finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8);
+}
+
+int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k, float* D,
+                     int64_t* I) {
+    TRY(check_ready(h, true));
+    TRY(check_search_args(h, n, x, nprobe, k, D, I));
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const void* xd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    TRY(h->ws_keys.reserve((size_t)n * nprobe * 8));
+    TRY(h->ws_cdis.reserve((size_t)n * nprobe * 4));
+    void *Dd, *Id;
+    bool copyD, copyI;
+    TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
+    TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
+    // IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081): quantizer->search, then search_knn_with_key
+    TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
+    TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
+                 (float*)Dd, (int64_t*)Id, 0));
+    return finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8);
+}
+
+int vlq_ivfpq_query_tables(vlq_ivfpq_t h, int64_t n, const float* x, int inner_product, float* out) {
+    TRY(check_ready(h, false));
+    if (n < 0 || (n > 0 && (!x || !out))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const size_t E = (size_t)h->M * h->ksub;
+    const void* xd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    TRY(h->ws_qtab.reserve((size_t)n * E * 4));
+    vlq::launch_pq_tables((const float*)xd, n, h->d, h->pq.as<float>(), h->M, h->ksub, h->dsub, nullptr,
+                          inner_product ? 0 : 1, h->ws_qtab.as<float>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->ws_qtab.p, (size_t)n * E * 4, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out) {
+    TRY(check_ready(h, false));
+    if (!out) return fail(VLQ_ERR_INVALID, "null out");
+    if (!(h->by_residual && h->use_precomputed_table == 1))
+        return fail(VLQ_ERR_STATE, "precomputed table not in use");
+    TRY(set_dev(h));
+    TRY(ensure_term2(h));
+    HIP_TRY(hipMemcpyAsync(out, h->term2.p, (size_t)h->nlist * h->M * h->ksub * 4, hipMemcpyDefault, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h));
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (nq) *nq = h->stat_nq;
+    if (ncode) *ncode = st[0];
+    const int bad = (int)(st[1] & 0xffffffffu);
+    if (reset || bad) {
+        HIP_TRY(hipMemsetAsync(h->stats.p, 0, 16, h->stream));
+        if (reset) h->stat_nq = 0;
+    }
+    // the reference aborts the search on an out-of-range key (IndexIVFPQ.cpp:1008-1011)
+    if (bad) return fail(VLQ_ERR_INVALID, "a probe key >= nlist was passed to search_preassigned");
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_profile(vlq_ivfpq_t h, int enable) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    h->prof = enable != 0;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_profile_read(vlq_ivfpq_t h, double ms[3], int64_t* calls, int reset) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h));
+    drain_profile(h);
+    if (ms) { ms[0] = h->prof_ms[0]; ms[1] = h->prof_ms[1]; ms[2] = h->prof_ms[2]; }
+    if (calls) *calls = h->prof_calls;
+    if (reset) { h->prof_ms[0] = h->prof_ms[1] = h->prof_ms[2] = 0; h->prof_calls = 0; }
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes) {
+    TRY(check_ready(h, false));
+    if (n < 0 || (n > 0 && (!x || !assign || !codes))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const void* xd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    void *ad, *cd;
+    bool copy_a, copy_c;
+    TRY(stage_out(assign, (size_t)n * 8, h->ws_assign, &ad, &copy_a));
+    TRY(stage_out(codes, (size_t)n * h->M, h->ws_codes, &cd, &copy_c));
+    TRY(h->ws_misc.reserve((size_t)n * 4));
+    // quantizer->assign (IndexIVFPQ.cpp:205) = 1-NN search
+    TRY(coarse_dev(h, n, (const float*)xd, 1, h->ws_misc.as<float>(), (int64_t*)ad));
+    vlq::launch_residual_encode((const float*)xd, n, h->d, h->coarse.as<float>(), (const int64_t*)ad,
+                                h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub,
+                                (uint8_t*)cd, h->stream);
+    HIP_TRY(hipGetLastError());
+    return finish_outputs(h, copy_a, assign, ad, (size_t)n * 8, copy_c, codes, cd, (size_t)n * h->M);
+}
+
+int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids) {
+    TRY(check_ready(h, false));
+    if (n < 0 || (n > 0 && !x)) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    // encode on the device
+    std::vector<int64_t> assign((size_t)n);
+    DevBuf new_codes;
+    TRY(new_codes.reserve((size_t)n * h->M));
+    int rc = vlq_ivfpq_encode(h, n, x, assign.data(), new_codes.as<uint8_t>());
+    if (rc != VLQ_OK) { new_codes.release(); return rc; }
+    // host side: stable placement (append in input order, IndexIVFPQ.cpp:236-248)
+    std::vector<int64_t> cnt((size_t)h->nlist, 0);
+    for (int64_t i = 0; i < n; i++) if (assign[i] >= 0) cnt[assign[i]]++;
+    std::vector<int64_t> new_off((size_t)h->nlist + 1, 0);
+    for (int i = 0; i < h->nlist; i++)
+        new_off[i + 1] = new_off[i] + (h->h_list_off[i + 1] - h->h_list_off[i]) + cnt[i];
+    const int64_t new_total = new_off[h->nlist];
+    std::vector<uint8_t> hc((size_t)new_total * h->M);
+    std::vector<int64_t> hi((size_t)new_total);
+    // old content
+    std::vector<uint8_t> oc((size_t)h->ntotal * h->M);
+    std::vector<int64_t> oi((size_t)h->ntotal);
+    std::vector<uint8_t> nc((size_t)n * h->M);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->ntotal > 0) {
+        HIP_TRY(hipMemcpy(oc.data(), h->codes.p, oc.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(oi.data(), h->ids.p, oi.size() * 8, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(nc.data(), new_codes.p, nc.size(), hipMemcpyDeviceToHost));
+    new_codes.release();
+    std::vector<int64_t> ids_in;
+    if (xids) {
+        ids_in.resize((size_t)n);
+        HIP_TRY(hipMemcpy(ids_in.data(), xids, (size_t)n * 8, hipMemcpyDefault));
+    }
+    std::vector<int64_t> fill((size_t)h->nlist);
+    for (int i = 0; i < h->nlist; i++) {
+        const int64_t o = h->h_list_off[i], len = h->h_list_off[i + 1] - o;
+        if (len > 0) {
+            memcpy(&hc[(size_t)new_off[i] * h->M], &oc[(size_t)o * h->M], (size_t)len * h->M);
+            memcpy(&hi[(size_t)new_off[i]], &oi[(size_t)o], (size_t)len * 8);
+        }
+        fill[i] = new_off[i] + len;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t key = assign[i];
+        if (key < 0) continue;                                  // IndexIVFPQ.cpp:238-243
+        const int64_t p = fill[key]++;
+        memcpy(&hc[(size_t)p * h->M], &nc[(size_t)i * h->M], (size_t)h->M);
+        hi[(size_t)p] = xids ? ids_in[(size_t)i] : h->ntotal + i;   // IndexIVFPQ.cpp:244
+    }
+    const int64_t ntotal_after = h->ntotal + n;                 // IndexIVFPQ.cpp:271
+    rc = vlq_ivfpq_set_lists(h, hc.data(), hi.data(), new_off.data());
+    if (rc != VLQ_OK) return rc;
+    h->ntotal = ntotal_after;
+    return VLQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Host-side launch interface of the HIP kernels (kernels.hip).  Everything takes
+// raw device pointers and a stream; no allocation, no synchronisation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vlq {
+
+// row norms in the reference's SSE order (utils.cpp:538-556, :675-682)
+void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s);
+
+// out[i][j] = (qn[i] + cn[j]) - 2 * <q_i, c_j>   (utils.cpp:884), inner product =
+// k-ordered f32 MFMA chain.  out is [nq][nlist].
+void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s);
+
+// < 20 queries: direct fvec_L2sqr per pair (utils.cpp:757-786)
+void launch_coarse_distances_direct(const float* q, const float* c, float* out, int64_t nq,
+                                    int nlist, int d, hipStream_t s);
+
+// per row: the nprobe smallest (distance, column), ascending; pads -1 / FLT_MAX
+void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, float* cdis,
+                          int64_t* keys, hipStream_t s);
+
+// PQ tables.  mode 0: <x_m, cent_mj>  (ProductQuantizer.cpp:424-436)
+//             mode 1: |x_m - cent_mj|^2 (ProductQuantizer.cpp:410-422)
+//             mode 2: rnorm[m][j] + 2 <x_m, cent_mj>  (IndexIVFPQ.cpp:423-429)
+// x [nv][d], cent [M][ksub][dsub], out [nv][M][ksub]
+void launch_pq_tables(const float* x, int64_t nv, int d, const float* cent, int M, int ksub,
+                      int dsub, const float* rnorm, int mode, float* out, hipStream_t s);
+
+struct ScanArgs {
+    const uint8_t* codes;        // [ntotal][M] list-contiguous
+    const int64_t* ids;          // [ntotal]
+    const int64_t* list_off;     // [nlist+1]
+    const float* term2;          // [nlist][M*ksub]   (table mode 1) or nullptr
+    const float* qtab;           // [nq][M*ksub] per-query table (ip table or distance table)
+    const float* queries;        // [nq][d]          (table mode 0 only)
+    const float* coarse;         // [nlist][d]       (table mode 0 only)
+    const float* pq_cent;        // [M][ksub][dsub]  (table mode 0 only)
+    const int64_t* keys;         // [nq][nprobe]
+    const float* coarse_dis;     // [nq][nprobe]
+    float* D;                    // [nq][k]
+    int64_t* I;                  // [nq][k]
+    unsigned long long* ncode;   // accumulated number of visited codes
+    int* bad_key;                // set to 1 if a key >= nlist was met
+    int64_t nq;
+    int nprobe, k, M, ksub, dsub, d, nlist;
+    int table_mode;              // 0: by_residual, no table; 1: by_residual + term2; 2: not by_residual
+    int64_t max_codes;
+    int store_pairs;
+};
+void launch_scan(const ScanArgs& a, hipStream_t s);
+
+// encode path (IndexIVFPQ.cpp:192-231, ProductQuantizer.cpp:311-336)
+void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,
+                            const int64_t* assign, int by_residual, const float* cent, int M,
+                            int ksub, int dsub, uint8_t* codes, hipStream_t s);
+
+}  // namespace vlq

@@ -1,0 +1,604 @@
+// HIP kernels of the IVFPQ search path for gfx950 (MI355X, CDNA4).
+//
+// Stage map (reference function -> kernel):
+//   fvec_norms_L2sqr            utils.cpp:675-682        -> row_norms_kernel
+//   knn_L2sqr_blas (sgemm part) utils.cpp:834-901        -> coarse_dist_kernel   (f32 MFMA)
+//   knn_L2sqr_blas (heap part)  utils.cpp:876-893        -> coarse_select_kernel (wave select)
+//   compute_inner_prod_table    ProductQuantizer.cpp:424 -> pq_tables_kernel
+//   precompute_table            IndexIVFPQ.cpp:392-429   -> pq_tables_kernel (mode 2)
+//   precompute_list_tables_L2 + scan_list_with_table + heap
+//                               IndexIVFPQ.cpp:631-690, :781-802, :964-1060
+//                                                        -> scan_kernel
+//   compute_code                ProductQuantizer.cpp:311-336 -> encode_kernel
+#include "kernels.h"
+#include "sse_order.cuh"
+#include "wave_topk.cuh"
+
+namespace vlq {
+
+#define FLT_MAX_F 3.402823466e+38f
+
+// ---------------------------------------------------------------------------
+// row norms
+// ---------------------------------------------------------------------------
+__global__ void row_norms_kernel(const float* __restrict__ x, int64_t n, int d,
+                                 float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* xi = x + i * d;
+    out[i] = norm_sse_order([&](int c) { return xi[c]; }, d);
+}
+
+void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n,
+                       d, out);
+}
+
+// ---------------------------------------------------------------------------
+// coarse distances: 128x128 output tile per 256-thread workgroup, 4 waves as 2x2,
+// each wave a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators.
+// The MFMA consumes k in pairs (lane>>5 selects k parity), so the LDS tiles are
+// stored de-interleaved (even k | odd k): every lane then reads 4 consecutive
+// k-pairs with one ds_read_b128 and the accumulation runs over k = 0,1,2,... in
+// natural order -- bit-identical to a scalar fmaf chain.
+// Row stride KC/2+4 floats keeps the b128 reads bank-conflict free.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KC>
+__global__ __launch_bounds__(256) void coarse_dist_kernel(
+    const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
+    const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d) {
+    constexpr int S = KC / 2 + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2 mat][2 parity][128][S]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t i0 = (int64_t)blockIdx.y * 128;
+    const int j0 = blockIdx.x * 128;
+    const bool vec_ok = (d % 4 == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < d; k0 += KC) {
+        for (int f = t; f < 128 * (KC / 4); f += 256) {
+            const int row = f / (KC / 4), v = f % (KC / 4);
+            const int kk = k0 + 4 * v;
+#pragma unroll
+            for (int mat = 0; mat < 2; mat++) {
+                const float* base = mat == 0 ? Q : Cn;
+                const int64_t grow = mat == 0 ? i0 + row : (int64_t)j0 + row;
+                const int64_t lim = mat == 0 ? nq : (int64_t)nlist;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grow < lim) {
+                    const float* p = base + grow * d + kk;
+                    if (vec_ok && kk + 4 <= d) {
+                        x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (kk + 0 < d) x.x = p[0];
+                        if (kk + 1 < d) x.y = p[1];
+                        if (kk + 2 < d) x.z = p[2];
+                        if (kk + 3 < d) x.w = p[3];
+                    }
+                }
+                float* even = sm + ((mat * 2 + 0) * 128 + row) * S + 2 * v;
+                float* odd = sm + ((mat * 2 + 1) * 128 + row) * S + 2 * v;
+                *reinterpret_cast<float2*>(even) = make_float2(x.x, x.z);
+                *reinterpret_cast<float2*>(odd) = make_float2(x.y, x.w);
+            }
+        }
+        __syncthreads();
+        const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+        for (int u = 0; u < KC / 8; u++) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++) {
+                a[ti] = *reinterpret_cast<const float4*>(
+                    sm + ((0 * 2 + h) * 128 + wr * 64 + ti * 32 + r) * S + 4 * u);
+                b[ti] = *reinterpret_cast<const float4*>(
+                    sm + ((1 * 2 + h) * 128 + wc * 64 + ti * 32 + r) * S + 4 * u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+                    for (int tj = 0; tj < 2; tj++) {
+                        const float av = e == 0 ? a[ti].x : e == 1 ? a[ti].y : e == 2 ? a[ti].z : a[ti].w;
+                        const float bv = e == 0 ? b[tj].x : e == 1 ? b[tj].y : e == 2 ? b[tj].z : b[tj].w;
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][tj], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int h = lane >> 5, cidx = lane & 31;
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const int col = j0 + wc * 64 + tj * 32 + cidx;
+            const float cnv = col < nlist ? cn[col] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t row = i0 + wr * 64 + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (row < nq && col < nlist) {
+                    const float ip = acc[ti][tj][reg];
+                    // (x_norm + y_norm) - 2*ip, utils.cpp:884
+                    out[row * nlist + col] =
+                        __fsub_rn(__fadd_rn(qn[row], cnv), __fmul_rn(2.f, ip));
+                }
+            }
+        }
+}
+
+void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s) {
+    if (nq <= 0 || nlist <= 0) return;
+    constexpr int KC = 64;
+    const size_t smem = 2 * 2 * 128 * (KC / 2 + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_kernel<KC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
+    hipLaunchKernelGGL(coarse_dist_kernel<KC>, grid, dim3(256), smem, s, q, c, qn, cn, out, nq,
+                       nlist, d);
+}
+
+// ---------------------------------------------------------------------------
+// coarse distances for batches of < 20 queries: the reference then skips BLAS and
+// calls fvec_L2sqr per (query, centroid) pair (knn_L2sqr_sse, utils.cpp:757-786,
+// dispatch :935-946).  Same operation order here, one thread per centroid.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_direct_kernel(const float* __restrict__ Q,
+                                                            const float* __restrict__ Cn,
+                                                            float* __restrict__ out, int64_t nq,
+                                                            int nlist, int d) {
+    extern __shared__ __attribute__((aligned(16))) float sq[];   // [d]
+    const int64_t i = blockIdx.y;
+    for (int c = threadIdx.x; c < d; c += 256) sq[c] = Q[i * d + c];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nlist) return;
+    const float* cj = Cn + (size_t)j * d;
+    out[i * nlist + j] =
+        l2sqr_sse_order([&](int c) { return sq[c]; }, [&](int c) { return cj[c]; }, d);
+}
+
+void launch_coarse_distances_direct(const float* q, const float* c, float* out, int64_t nq,
+                                    int nlist, int d, hipStream_t s) {
+    if (nq <= 0 || nlist <= 0) return;
+    dim3 grid((unsigned)((nlist + 255) / 256), (unsigned)nq);
+    hipLaunchKernelGGL(coarse_direct_kernel, grid, dim3(256), (size_t)d * sizeof(float), s, q, c,
+                       out, nq, nlist, d);
+}
+
+// ---------------------------------------------------------------------------
+// coarse select: one wave per query row, running selection of the nprobe
+// smallest (distance, centroid id).
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restrict__ dist,
+                                                            int64_t nq, int nlist, int nprobe,
+                                                            float* __restrict__ cdis,
+                                                            int64_t* __restrict__ keys) {
+    __shared__ u64 queue[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;   // whole wave; no workgroup barrier below
+    WaveSelect<KPL> sel;
+    sel.init(nprobe, queue[wave], lane);
+    const float* row = dist + q * nlist;
+    for (int j0 = 0; j0 < nlist; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < nlist;
+        const float v = valid ? row[j] : 0.f;
+        sel.offer(v, (uint32_t)j, valid);
+    }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < nprobe) {
+            const u64 key = sel.best[r];
+            const bool miss = key == kMaxKey;
+            cdis[q * nprobe + e] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+            keys[q * nprobe + e] = miss ? -1 : (int64_t)(uint32_t)key;
+        }
+    }
+}
+
+void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, float* cdis,
+                          int64_t* keys, hipStream_t s) {
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (nprobe <= 64)
+        hipLaunchKernelGGL(coarse_select_kernel<1>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+    else if (nprobe <= 256)
+        hipLaunchKernelGGL(coarse_select_kernel<4>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+    else
+        hipLaunchKernelGGL(coarse_select_kernel<16>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+}
+
+// ---------------------------------------------------------------------------
+// PQ tables: out[v][m][j] for a tile of VT vectors x one sub-quantizer per
+// workgroup.  The sub-quantizer's ksub centroids sit in LDS with a padded row
+// (dsub+1) so that consecutive j hit distinct banks.
+// ---------------------------------------------------------------------------
+constexpr int kTableVT = 32;
+
+__global__ __launch_bounds__(256) void pq_tables_kernel(
+    const float* __restrict__ x, int64_t nv, int d, const float* __restrict__ cent, int M,
+    int ksub, int dsub, const float* __restrict__ rnorm, int mode, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ds1 = dsub + 1;
+    float* scent = sm;                  // [ksub][dsub+1]
+    float* sx = sm + ksub * ds1;        // [VT][dsub]
+    const int m = blockIdx.y;
+    const int64_t v0 = (int64_t)blockIdx.x * kTableVT;
+    const int t = threadIdx.x;
+    const float* cm = cent + (size_t)m * ksub * dsub;
+    for (int e = t; e < ksub * dsub; e += 256) scent[(e / dsub) * ds1 + (e % dsub)] = cm[e];
+    for (int e = t; e < kTableVT * dsub; e += 256) {
+        const int64_t v = v0 + e / dsub;
+        sx[e] = v < nv ? x[v * d + m * dsub + (e % dsub)] : 0.f;
+    }
+    __syncthreads();
+    for (int e = t; e < kTableVT * ksub; e += 256) {
+        const int vl = e / ksub, j = e % ksub;
+        const int64_t v = v0 + vl;
+        if (v >= nv) break;
+        const float* xv = sx + vl * dsub;
+        const float* cj = scent + j * ds1;
+        float r;
+        if (mode == 1) {
+            r = l2sqr_sse_order([&](int c) { return xv[c]; }, [&](int c) { return cj[c]; }, dsub);
+        } else {
+            r = ip_sse_order([&](int c) { return xv[c]; }, [&](int c) { return cj[c]; }, dsub);
+            if (mode == 2)  // fvec_madd(r_norms, 2.0, tab): a + bf*b (utils.cpp:1832-1853)
+                r = __fadd_rn(rnorm[m * ksub + j], __fmul_rn(2.f, r));
+        }
+        out[((size_t)v * M + m) * ksub + j] = r;
+    }
+}
+
+void launch_pq_tables(const float* x, int64_t nv, int d, const float* cent, int M, int ksub,
+                      int dsub, const float* rnorm, int mode, float* out, hipStream_t s) {
+    if (nv <= 0) return;
+    const size_t smem = ((size_t)ksub * (dsub + 1) + (size_t)kTableVT * dsub) * sizeof(float);
+    dim3 grid((unsigned)((nv + kTableVT - 1) / kTableVT), (unsigned)M);
+    hipLaunchKernelGGL(pq_tables_kernel, grid, dim3(256), smem, s, x, nv, d, cent, M, ksub, dsub,
+                       rnorm, mode, out);
+}
+
+// ---------------------------------------------------------------------------
+// list scan.  One 256-thread workgroup (4 waves) per query:
+//   * the per-query table part stays in registers for the whole query
+//     (FAST path: 16 entries per thread, already multiplied by -2);
+//   * per probe: term2[key] (16 KB at M=16,ksub=256) is prefetched from L2/MALL one
+//     probe ahead, combined as  t2 + (-2*ip)  -- the exact fvec_madd value,
+//     IndexIVFPQ.cpp:641-644 -- and written to one of two LDS LUT buffers, so
+//     building LUT p+1 overlaps scanning with LUT p and one barrier per probe
+//     suffices;
+//   * the scan streams the list's packed codes with one 16-byte load per lane
+//     (coalesced 1 KiB per wave-instruction) and sums  dis0 + t[0] + ... + t[M-1]
+//     strictly left to right (IndexIVFPQ.cpp:788-794);
+//   * each wave keeps a running selection (wave_topk.cuh); the four are merged
+//     at the end and the winners' ids are fetched (ids are never touched in the
+//     scan itself).
+// ---------------------------------------------------------------------------
+template <int KPL, bool FAST16>
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a, int nbuf, int lut_region) {
+    // LDS: [lut_region bytes: LUT buffers, later the 4 x k merge area][queue][cum][residual]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int E = a.M * a.ksub;
+    float* lut = reinterpret_cast<float*>(smraw);                       // [nbuf][E]
+    u64* queue = reinterpret_cast<u64*>(smraw + lut_region);            // [4][64]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);        // [nprobe+1]
+    float* sres = reinterpret_cast<float*>(cum + a.nprobe + 1);         // [d] (table mode 0)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t q = blockIdx.x;
+    const int64_t* kq = a.keys + q * a.nprobe;
+    const float* cq = a.coarse_dis + q * a.nprobe;
+    const float* qt = a.qtab ? a.qtab + q * E : nullptr;
+
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    // FAST16: 4 float4 per thread of -2 * ip_table (mode 1)
+    float4 m2t3[4];
+    float4 t2r[4];
+    if (FAST16) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float4 v = reinterpret_cast<const float4*>(qt)[i * 256 + t];
+            m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
+                                  __fmul_rn(-2.f, v.w));
+        }
+        const int64_t key0 = a.nprobe > 0 ? kq[0] : -1;
+        if (key0 >= 0 && key0 < a.nlist) {
+            const float4* src = reinterpret_cast<const float4*>(a.term2 + key0 * E);
+#pragma unroll
+            for (int i = 0; i < 4; i++) t2r[i] = src[i * 256 + t];
+        }
+    } else if (a.table_mode == 2) {
+        // not by_residual: one distance table per query (IndexIVFPQ.cpp:558-559)
+        for (int e = t; e < E; e += 256) lut[e] = qt[e];
+        __syncthreads();
+    }
+
+    uint32_t pos0 = 0;
+    int64_t nscan = 0;
+    int buf = 0;
+    int ik = 0;
+    bool badkey = false;
+    for (; ik < a.nprobe; ik++) {
+        const int64_t key = kq[ik];
+        if (t == 0) cum[ik] = pos0;
+        int64_t len = 0, off = 0;
+        if (key >= a.nlist) badkey = true;                  // IndexIVFPQ.cpp:1008-1011
+        const bool live = key >= 0 && key < a.nlist;
+        if (live) { off = a.list_off[key]; len = a.list_off[key + 1] - off; }
+        float dis0 = 0.f;
+
+        if (len > 0) {
+            float* L = lut + (size_t)buf * E;
+            if (FAST16) {
+                dis0 = cq[ik];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float4 s;
+                    s.x = __fadd_rn(t2r[i].x, m2t3[i].x);
+                    s.y = __fadd_rn(t2r[i].y, m2t3[i].y);
+                    s.z = __fadd_rn(t2r[i].z, m2t3[i].z);
+                    s.w = __fadd_rn(t2r[i].w, m2t3[i].w);
+                    reinterpret_cast<float4*>(L)[i * 256 + t] = s;
+                }
+            } else if (a.table_mode == 1) {
+                dis0 = cq[ik];
+                const float* t2 = a.term2 + key * E;
+                for (int e = t; e < E; e += 256)
+                    L[e] = __fadd_rn(t2[e], __fmul_rn(-2.f, qt[e]));
+            } else if (a.table_mode == 0) {
+                // residual tables: compute_residual + compute_distance_table
+                // (IndexIVFPQ.cpp:636-637)
+                const float* c = a.coarse + key * a.d;
+                const float* qv = a.queries + q * a.d;
+                for (int e = t; e < a.d; e += 256) sres[e] = __fsub_rn(qv[e], c[e]);
+                __syncthreads();
+                for (int e = t; e < E; e += 256) {
+                    const int m = e / a.ksub;
+                    const float* xv = sres + m * a.dsub;
+                    const float* cj = a.pq_cent + (size_t)e * a.dsub;
+                    L[e] = l2sqr_sse_order([&](int c2) { return xv[c2]; },
+                                           [&](int c2) { return cj[c2]; }, a.dsub);
+                }
+            }
+        }
+        if (FAST16 && ik + 1 < a.nprobe) {
+            const int64_t kn = kq[ik + 1];
+            if (kn >= 0 && kn < a.nlist) {
+                const float4* src = reinterpret_cast<const float4*>(a.term2 + kn * E);
+#pragma unroll
+                for (int i = 0; i < 4; i++) t2r[i] = src[i * 256 + t];
+            }
+        }
+        if (len > 0) {
+            if (a.table_mode != 2) __syncthreads();
+            const float* L = a.table_mode == 2 ? lut : lut + (size_t)buf * E;
+            if (FAST16) {
+                const uint4* cp = reinterpret_cast<const uint4*>(a.codes + off * 16);
+                for (int64_t j0 = (int64_t)wave * 64; j0 < len; j0 += 256) {
+                    const int64_t j = j0 + lane;
+                    const bool valid = j < len;
+                    float dis = 0.f;
+                    if (valid) {
+                        const uint4 c = cp[j];
+                        dis = dis0;
+                        dis = __fadd_rn(dis, L[0 * 256 + (c.x & 255u)]);
+                        dis = __fadd_rn(dis, L[1 * 256 + ((c.x >> 8) & 255u)]);
+                        dis = __fadd_rn(dis, L[2 * 256 + ((c.x >> 16) & 255u)]);
+                        dis = __fadd_rn(dis, L[3 * 256 + (c.x >> 24)]);
+                        dis = __fadd_rn(dis, L[4 * 256 + (c.y & 255u)]);
+                        dis = __fadd_rn(dis, L[5 * 256 + ((c.y >> 8) & 255u)]);
+                        dis = __fadd_rn(dis, L[6 * 256 + ((c.y >> 16) & 255u)]);
+                        dis = __fadd_rn(dis, L[7 * 256 + (c.y >> 24)]);
+                        dis = __fadd_rn(dis, L[8 * 256 + (c.z & 255u)]);
+                        dis = __fadd_rn(dis, L[9 * 256 + ((c.z >> 8) & 255u)]);
+                        dis = __fadd_rn(dis, L[10 * 256 + ((c.z >> 16) & 255u)]);
+                        dis = __fadd_rn(dis, L[11 * 256 + (c.z >> 24)]);
+                        dis = __fadd_rn(dis, L[12 * 256 + (c.w & 255u)]);
+                        dis = __fadd_rn(dis, L[13 * 256 + ((c.w >> 8) & 255u)]);
+                        dis = __fadd_rn(dis, L[14 * 256 + ((c.w >> 16) & 255u)]);
+                        dis = __fadd_rn(dis, L[15 * 256 + (c.w >> 24)]);
+                    }
+                    sel.offer(dis, pos0 + (uint32_t)j, valid);
+                }
+            } else {
+                const uint8_t* cp = a.codes + off * a.M;
+                for (int64_t j0 = (int64_t)wave * 64; j0 < len; j0 += 256) {
+                    const int64_t j = j0 + lane;
+                    const bool valid = j < len;
+                    float dis = 0.f;
+                    if (valid) {
+                        const uint8_t* cj = cp + j * a.M;
+                        dis = dis0;
+                        const float* tab = L;
+                        if ((a.M & 3) == 0) {
+                            const uint32_t* cw = reinterpret_cast<const uint32_t*>(cj);
+                            for (int w = 0; w < a.M / 4; w++) {
+                                const uint32_t c = cw[w];
+                                dis = __fadd_rn(dis, tab[c & 255u]); tab += a.ksub;
+                                dis = __fadd_rn(dis, tab[(c >> 8) & 255u]); tab += a.ksub;
+                                dis = __fadd_rn(dis, tab[(c >> 16) & 255u]); tab += a.ksub;
+                                dis = __fadd_rn(dis, tab[c >> 24]); tab += a.ksub;
+                            }
+                        } else {
+                            for (int m = 0; m < a.M; m++) {
+                                dis = __fadd_rn(dis, tab[cj[m]]);
+                                tab += a.ksub;
+                            }
+                        }
+                    }
+                    sel.offer(dis, pos0 + (uint32_t)j, valid);
+                }
+            }
+            if (nbuf == 2) buf ^= 1;
+            else if (a.table_mode != 2) __syncthreads();   // single buffer: scan done before rebuild
+        }
+        nscan += len;
+        pos0 += (uint32_t)len;
+        if (a.max_codes && nscan >= a.max_codes) { ik++; break; }   // IndexIVFPQ.cpp:1033
+    }
+    if (t == 0)
+        for (int i = ik; i <= a.nprobe; i++) cum[i] = pos0;
+
+    // ---- merge the four waves' selections, emit ----
+    sel.flush();
+    __syncthreads();                       // LUT buffers are free from here on
+    u64* mb = reinterpret_cast<u64*>(smraw);   // [4][k], aliases the LUT
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < a.k) mb[wave * a.k + e] = sel.best[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < 4; w++)
+        for (int e0 = 0; e0 < a.k; e0 += 64) {
+            const int e = e0 + lane;
+            const bool valid = e < a.k;
+            const u64 key = valid ? mb[w * a.k + e] : kMaxKey;
+            sel.offer_key(key, valid);
+        }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e >= a.k) continue;
+        const u64 key = sel.best[r];
+        float dis = FLT_MAX_F;
+        int64_t id = -1;
+        if (key != kMaxKey) {
+            dis = ordered_to_f32((uint32_t)(key >> 32));
+            const uint32_t pos = (uint32_t)key;
+            int lo = 0, hi = a.nprobe;      // find probe p with cum[p] <= pos < cum[p+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (cum[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const int64_t lkey = kq[lo];
+            const int64_t o = pos - cum[lo];
+            id = a.store_pairs ? (lkey << 32 | o) : a.ids[a.list_off[lkey] + o];
+        }
+        a.D[q * a.k + e] = dis;
+        a.I[q * a.k + e] = id;
+    }
+    if (lane == 0) {
+        atomicAdd(a.ncode, (unsigned long long)nscan);
+        if (badkey) *a.bad_key = 1;
+    }
+}
+
+template <int KPL, bool FAST16>
+static void launch_scan_t(const ScanArgs& a, int nbuf, int lut_region, size_t smem, hipStream_t s) {
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<KPL, FAST16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL((scan_kernel<KPL, FAST16>), dim3((unsigned)a.nq), dim3(256), smem, s, a, nbuf,
+                       lut_region);
+}
+
+void launch_scan(const ScanArgs& a, hipStream_t s) {
+    if (a.nq <= 0) return;
+    const size_t E = (size_t)a.M * a.ksub;
+    const size_t tail = 4 * 64 * 8 + ((size_t)a.nprobe + 1) * 4 + (size_t)a.d * 4 + 16;
+    int nbuf = (a.table_mode == 2) ? 1 : 2;
+    if (2 * E * 4 + tail > 150 * 1024) nbuf = 1;
+    size_t lutb = (size_t)nbuf * E * 4;
+    const size_t merge = (size_t)4 * a.k * 8;       // merge area aliases the LUT buffers
+    if (lutb < merge) lutb = merge;
+    lutb = (lutb + 15) & ~(size_t)15;
+    const int lut_region = (int)lutb;
+    const size_t smem = lutb + tail;
+    const bool fast = a.table_mode == 1 && a.M == 16 && a.ksub == 256 && nbuf == 2;
+    if (fast) {
+        if (a.k <= 64) launch_scan_t<1, true>(a, nbuf, lut_region, smem, s);
+        else if (a.k <= 256) launch_scan_t<4, true>(a, nbuf, lut_region, smem, s);
+        else launch_scan_t<16, true>(a, nbuf, lut_region, smem, s);
+    } else {
+        if (a.k <= 64) launch_scan_t<1, false>(a, nbuf, lut_region, smem, s);
+        else if (a.k <= 256) launch_scan_t<4, false>(a, nbuf, lut_region, smem, s);
+        else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode: residual to the assigned centroid, then per sub-quantizer the first
+// minimum of fvec_L2sqr (ProductQuantizer.cpp:311-336: strict '<', mindis = 1e20).
+// One wave per vector: lane j scans centroids j, j+64, ... and the wave reduces
+// (distance, index) lexicographically, which is exactly "first minimum wins".
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encode_kernel(
+    const float* __restrict__ x, int64_t n, int d, const float* __restrict__ coarse,
+    const int64_t* __restrict__ assign, int by_residual, const float* __restrict__ cent, int M,
+    int ksub, int dsub, uint8_t* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][d]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+    if (v >= n) return;
+    float* r = sm + wave * d;
+    const int64_t key = assign ? assign[v] : -1;
+    for (int c = lane; c < d; c += 64) {
+        float xv = x[v * d + c];
+        if (by_residual) xv = key < 0 ? 0.f : __fsub_rn(xv, coarse[key * d + c]);   // IndexIVFPQ.cpp:219-225
+        r[c] = xv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int m = 0; m < M; m++) {
+        const float* xs = r + m * dsub;
+        float best = 1e20f;
+        int bi = -1;
+        for (int j = lane; j < ksub; j += 64) {
+            const float* cj = cent + ((size_t)m * ksub + j) * dsub;
+            const float dis = l2sqr_sse_order([&](int c) { return xs[c]; }, [&](int c) { return cj[c]; }, dsub);
+            if (dis < best) { best = dis; bi = j; }
+        }
+        // lexicographic (dis, idx) min across lanes; idx -1 (no candidate < 1e20) loses
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ob = __shfl_xor(best, sft, 64);
+            const int oi = __shfl_xor(bi, sft, 64);
+            const bool take = (oi >= 0) && (bi < 0 || ob < best || (ob == best && oi < bi));
+            if (take) { best = ob; bi = oi; }
+        }
+        if (lane == 0) codes[v * M + m] = (uint8_t)bi;
+    }
+}
+
+void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,
+                            const int64_t* assign, int by_residual, const float* cent, int M,
+                            int ksub, int dsub, uint8_t* codes, hipStream_t s) {
+    if (n <= 0) return;
+    const size_t smem = (size_t)4 * d * sizeof(float);
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), smem, s, x, n, d,
+                       coarse, assign, by_residual, cent, M, ksub, dsub, codes);
+}
+
+}  // namespace vlq

@@ -1,0 +1,176 @@
+"""Python handle over the C ABI.  Arguments may be numpy arrays (host) or torch
+tensors (host or device: only .data_ptr() is taken -- torch is plumbing for device
+memory and streams, never compute)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def _is_torch(a):
+    return hasattr(a, "data_ptr") and hasattr(a, "is_contiguous")
+
+
+def _ptr(a, np_dtype=None):
+    """(pointer, keepalive) of a numpy array or torch tensor; None -> NULL."""
+    if a is None:
+        return None, None
+    if _is_torch(a):
+        if not a.is_contiguous():
+            a = a.contiguous()
+        return C.c_void_p(a.data_ptr()), a
+    a = np.ascontiguousarray(a, dtype=np_dtype)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
+class GpuIVFPQ:
+    """Mirror of the data-carrying surface of faiss::gpu::GpuIndexIVFPQ
+    (gpu/GpuIndexIVFPQ.h:41-234) / faiss::IndexIVFPQ (IndexIVFPQ.h:29-164) for the
+    search path: construct, copy trained state in, search."""
+
+    def __init__(self, d, nlist, M, nbits, device=0):
+        self.d, self.nlist, self.M, self.nbits = d, nlist, M, nbits
+        self.ksub = 1 << nbits
+        self._h = C.c_void_p()
+        check(lib().vlq_ivfpq_create(C.byref(self._h), C.c_int(device), C.c_int(d), C.c_int(nlist),
+                                     C.c_int(M), C.c_int(nbits)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().vlq_ivfpq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- state ------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        check(lib().vlq_ivfpq_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def set_coarse_centroids(self, c):
+        p, _k = _ptr(c, np.float32)
+        check(lib().vlq_ivfpq_set_coarse_centroids(self._h, p))
+
+    def set_pq_centroids(self, c):
+        p, _k = _ptr(c, np.float32)
+        check(lib().vlq_ivfpq_set_pq_centroids(self._h, p))
+
+    def set_search_options(self, by_residual=True, use_precomputed_table=1, max_codes=0):
+        check(lib().vlq_ivfpq_set_search_options(self._h, C.c_int(int(by_residual)),
+                                                 C.c_int(use_precomputed_table), C.c_int64(max_codes)))
+
+    def set_lists(self, codes, ids, list_offsets):
+        pc, _a = _ptr(codes, np.uint8)
+        pi, _b = _ptr(ids, np.int64)
+        po, _c = _ptr(list_offsets, np.int64)
+        check(lib().vlq_ivfpq_set_lists(self._h, pc, pi, po))
+
+    @property
+    def ntotal(self):
+        return int(lib().vlq_ivfpq_ntotal(self._h))
+
+    def list_length(self, i):
+        n = C.c_int64()
+        check(lib().vlq_ivfpq_list_length(self._h, C.c_int(i), C.byref(n)))
+        return n.value
+
+    def get_list(self, i):
+        n = self.list_length(i)
+        codes = np.empty((n, self.M), np.uint8)
+        ids = np.empty((n,), np.int64)
+        check(lib().vlq_ivfpq_get_list(self._h, C.c_int(i), codes.ctypes.data_as(C.c_void_p),
+                                       ids.ctypes.data_as(C.c_void_p)))
+        return codes, ids
+
+    # --- add --------------------------------------------------------------
+    def add(self, x, xids=None):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        pi, _b = _ptr(xids, np.int64)
+        check(lib().vlq_ivfpq_add(self._h, C.c_int64(n), px, pi))
+
+    def encode(self, x):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        assign = np.empty((n,), np.int64)
+        codes = np.empty((n, self.M), np.uint8)
+        check(lib().vlq_ivfpq_encode(self._h, C.c_int64(n), px, assign.ctypes.data_as(C.c_void_p),
+                                     codes.ctypes.data_as(C.c_void_p)))
+        return assign, codes
+
+    # --- search -----------------------------------------------------------
+    def _out(self, out, shape, dtype, like):
+        if out is not None:
+            return out
+        if _is_torch(like) and like.is_cuda:
+            import torch
+            return torch.empty(shape, dtype={np.float32: torch.float32, np.int64: torch.int64}[dtype],
+                               device=like.device)
+        return np.empty(shape, dtype)
+
+    def search(self, x, nprobe, k, D=None, I=None):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        D = self._out(D, (n, k), np.float32, x)
+        I = self._out(I, (n, k), np.int64, x)
+        pD, _b = _ptr(D)
+        pI, _c = _ptr(I)
+        check(lib().vlq_ivfpq_search(self._h, C.c_int64(n), px, C.c_int(nprobe), C.c_int(k), pD, pI))
+        return D, I
+
+    def search_preassigned(self, x, keys, coarse_dis, k, store_pairs=False, D=None, I=None):
+        n = x.shape[0]
+        nprobe = keys.shape[1]
+        px, _a = _ptr(x, np.float32)
+        pk, _b = _ptr(keys, np.int64)
+        pc, _c = _ptr(coarse_dis, np.float32)
+        D = self._out(D, (n, k), np.float32, x)
+        I = self._out(I, (n, k), np.int64, x)
+        pD, _d = _ptr(D)
+        pI, _e = _ptr(I)
+        check(lib().vlq_ivfpq_search_preassigned(self._h, C.c_int64(n), px, pk, pc, C.c_int(nprobe),
+                                                 C.c_int(k), pD, pI, C.c_int(int(store_pairs))))
+        return D, I
+
+    def coarse_search(self, x, nprobe, cdis=None, keys=None):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        cdis = self._out(cdis, (n, nprobe), np.float32, x)
+        keys = self._out(keys, (n, nprobe), np.int64, x)
+        pc, _b = _ptr(cdis)
+        pk, _c = _ptr(keys)
+        check(lib().vlq_ivfpq_coarse_search(self._h, C.c_int64(n), px, C.c_int(nprobe), pc, pk))
+        return cdis, keys
+
+    # --- introspection ----------------------------------------------------
+    def query_tables(self, x, inner_product=True):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        out = np.empty((n, self.M, self.ksub), np.float32)
+        check(lib().vlq_ivfpq_query_tables(self._h, C.c_int64(n), px, C.c_int(int(inner_product)),
+                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def precomputed_table(self):
+        out = np.empty((self.nlist, self.M, self.ksub), np.float32)
+        check(lib().vlq_ivfpq_get_precomputed_table(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stats(self, reset=False):
+        nq, ncode = C.c_uint64(), C.c_uint64()
+        check(lib().vlq_ivfpq_stats(self._h, C.byref(nq), C.byref(ncode), C.c_int(int(reset))))
+        return nq.value, ncode.value
+
+    def profile(self, enable=True):
+        check(lib().vlq_ivfpq_profile(self._h, C.c_int(int(enable))))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * 3)()
+        calls = C.c_int64()
+        check(lib().vlq_ivfpq_profile_read(self._h, ms, C.byref(calls), C.c_int(int(reset))))
+        return {"coarse_ms": ms[0], "tables_ms": ms[1], "scan_ms": ms[2], "scan_calls": calls.value}
