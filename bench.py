@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of IVFPQ search on MI355X.
+
+Workload (BASELINE.json configs[1]): SIFT1M-shaped synthetic data, d=128,
+nlist=4096, M=16 x 8 bit, nprobe=32, k=10, batch of 10 000 queries per GPU
+(index replicated, query batches sharded over ranks, RCCL all-gather of the
+per-rank top-k: weak scaling).  One "step" = one search() of one query batch
+with queries and results resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  torch is used for device memory, streams,
+synthetic data/training set-up and torch.distributed; the timed region is the
+HIP library behind include/vlq_ivfpq.h only.  The oracle (oracle/) is used for
+the cpu_baseline leg and a parity spot check, never in the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ----------------------------------------------------------------------------
+# synthetic SIFT1M-shaped data (generator G1 of SURVEY.md §8d) and index set-up
+# ----------------------------------------------------------------------------
+def gmm(torch, gen, centres, n, sigma, dev):
+    pick = torch.randint(0, centres.shape[0], (n,), generator=gen, device=dev)
+    x = centres[pick] + sigma * torch.randn((n, centres.shape[1]), generator=gen, device=dev)
+    return torch.clamp(torch.round(x * 255.0), 0, 255).float()
+
+
+def kmeans(torch, x, k, niter, gen):
+    """Plain Lloyd (set-up only; training is outside the hot path)."""
+    n = x.shape[0]
+    cent = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
+    for _ in range(niter):
+        d2 = (cent * cent).sum(1)[None, :] - 2.0 * x @ cent.T
+        a = d2.argmin(1)
+        cnt = torch.bincount(a, minlength=k).float()
+        s = torch.zeros_like(cent).index_add_(0, a, x)
+        nz = cnt > 0
+        cent[nz] = s[nz] / cnt[nz, None]
+        if (~nz).any():   # re-seed empty clusters from random points
+            idx = torch.randint(0, n, (int((~nz).sum()),), generator=gen, device=x.device)
+            cent[~nz] = x[idx]
+    return cent
+
+
+def build_index(args, dev):
+    import torch
+    import vector_line_quantization_amd as vlq
+    d, nlist, M, nbits = args.d, args.nlist, args.M, 8
+    ksub, dsub = 1 << nbits, d // M
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    centres = torch.rand((args.gmm_centres, d), generator=gen, device=dev)
+    gen.manual_seed(11)
+    xt = gmm(torch, gen, centres, args.nt, args.sigma, dev)
+    gen.manual_seed(22)
+    xb = gmm(torch, gen, centres, args.nb, args.sigma, dev)
+    t0 = time.time()
+    gen.manual_seed(1234)
+    coarse = kmeans(torch, xt, nlist, 10, gen)
+    # residual PQ training set (IndexIVFPQ.cpp:73-104): subsample to 256*ksub points
+    ntr = min(args.nt, 256 * ksub)
+    xs = xt[torch.randperm(args.nt, generator=gen, device=dev)[:ntr]]
+    a = ((coarse * coarse).sum(1)[None, :] - 2.0 * xs @ coarse.T).argmin(1)
+    res = xs - coarse[a]
+    pq = torch.stack([kmeans(torch, res[:, m * dsub:(m + 1) * dsub].contiguous(), ksub, 25, gen)
+                      for m in range(M)])
+    torch.cuda.synchronize()
+    log("trained coarse+PQ in %.1fs" % (time.time() - t0))
+
+    g = vlq.GpuIVFPQ(d, nlist, M, nbits, device=dev.index or 0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.set_coarse_centroids(coarse.contiguous())
+    g.set_pq_centroids(pq.contiguous())
+    t0 = time.time()
+    for i0 in range(0, args.nb, 262144):          # device-side encode + append
+        g.add(xb[i0:i0 + 262144].contiguous())
+    torch.cuda.synchronize()
+    log("added %d vectors in %.1fs (HIP encode path)" % (args.nb, time.time() - t0))
+    return g, centres, coarse, pq, xb
+
+
+def list_stats(g, nlist):
+    lens = np.array([g.list_length(i) for i in range(nlist)], dtype=np.float64)
+    tot = lens.sum()
+    imb = float((lens * lens).sum() * nlist / (tot * tot)) if tot > 0 else 0.0   # IndexIVF.cpp:140-147
+    return lens, imb
+
+
+def oracle_copy(g, args, coarse, pq):
+    from oracle import pyoracle
+    codes, ids, off = [], [], [0]
+    for i in range(args.nlist):
+        c, ii = g.get_list(i)
+        codes.append(c)
+        ids.append(ii)
+        off.append(off[-1] + len(ii))
+    return pyoracle.OracleIndex(args.d, args.nlist, args.M, 8, coarse.cpu().numpy(), pq.cpu().numpy(),
+                                codes=np.concatenate(codes), ids=np.concatenate(ids),
+                                list_offsets=np.array(off, np.int64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--nb", type=int, default=1000000)
+    ap.add_argument("--nt", type=int, default=100000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--sigma", type=float, default=0.03)
+    ap.add_argument("--gmm-centres", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=10000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    g, centres, coarse, pq, xb = build_index(args, dev)
+    lens, imb = list_stats(g, args.nlist)
+
+    # per-rank query batch (weak scaling: every rank gets its own nq queries)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(33 + rank)
+    xq = gmm(torch, gen, centres, args.nq, args.sigma, dev)
+    D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
+    I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
+    if world > 1:
+        Dall = torch.empty((world * args.nq, args.k), dtype=torch.float32, device=dev)
+        Iall = torch.empty((world * args.nq, args.k), dtype=torch.int64, device=dev)
+
+    def step():
+        g.search(xq, args.nprobe, args.k, D=D, I=I)
+        if world > 1:   # per-shard top-k -> every rank (north star: RCCL all-gather over xGMI)
+            dist.all_gather_into_tensor(Dall, D)
+            dist.all_gather_into_tensor(Iall, I)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    g.stats(reset=True)
+    g.profile(True)
+    g.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = g.profile_read(reset=True)
+    g.profile(False)
+    _nq_stat, ncode = g.stats(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    steps = args.steps
+    qps = world * args.nq * steps / elapsed
+    ncode_per_launch = ncode / max(1, prof["scan_calls"])
+    scan_ms = prof["scan_ms"] / max(1, prof["scan_calls"])
+    code_bytes = ncode_per_launch * args.M           # B_scan = ncode * code_size
+    achieved = code_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    lut_bytes = args.nq * args.nprobe * args.M * 256 * 4.0
+
+    out = {
+        "metric": "queries/sec @ recall@1 (SIFT1M, nlist=4096 m=16 nprobe=32 k=10)",
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: SIFT1M-shaped GMM bytes, d=%d nb=%d nlist=%d M=%dx8bit "
+                               "nprobe=%d k=%d batch=%d queries/GPU, precomputed-table mode 1"
+                               % (args.d, args.nb, args.nlist, args.M, args.nprobe, args.k, args.nq),
+                   "parallelism": "index replicated, queries sharded x%d, all-gather of top-k" % world,
+                   "list_imbalance": round(imb, 3), "ncode_per_query": ncode_per_launch / args.nq},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "scan_kernel", "kernel_ms": scan_ms,
+                     "algorithmic_bytes": code_bytes,
+                     "lut_bytes_separate": lut_bytes,
+                     "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0},
+        "stage_ms": {"coarse": prof["coarse_ms"] / steps, "tables": prof["tables_ms"] / steps,
+                     "scan": prof["scan_ms"] / steps},
+    }
+
+    # ---- parity spot check + recall + CPU baseline (outside the timed region) ----
+    ox = oracle_copy(g, args, coarse, pq)
+    xq_h = xq.cpu().numpy()
+    D_h, I_h = D.cpu().numpy(), I.cpu().numpy()
+    nchk = min(512, args.nq)
+    Do, Io = ox.search(xq_h[:nchk], args.nprobe, args.k, canonical=True)
+    out["parity"] = {"queries_checked": nchk,
+                     "distance_bits_equal": bool(np.array_equal(D_h[:nchk].view(np.uint32), Do.view(np.uint32))),
+                     "label_mismatches": int((I_h[:nchk] != Io).sum())}
+    nr = min(1000, args.nq)
+    xqr = xq[:nr]
+    best = torch.full((nr,), float("inf"), device=dev)
+    arg = torch.zeros((nr,), dtype=torch.int64, device=dev)
+    qn = (xqr * xqr).sum(1)
+    for i0 in range(0, args.nb, 131072):
+        xbb = xb[i0:i0 + 131072]
+        d2 = qn[:, None] + (xbb * xbb).sum(1)[None, :] - 2.0 * xqr @ xbb.T
+        m, a = d2.min(1)
+        upd = m < best
+        best[upd] = m[upd]
+        arg[upd] = a[upd] + i0
+    gt = arg.cpu().numpy()
+    out["config"]["recall_at_1"] = float((I_h[:nr, 0] == gt).mean())
+    out["config"]["recall_1_at_10"] = float((I_h[:nr] == gt[:, None]).any(1).mean())
+
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        ncpu = min(args.cpu_queries, args.nq)
+        ox.search(xq_h[:min(ncpu, 1000)], args.nprobe, args.k)     # warm-up
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ox.search(xq_h[:ncpu], args.nprobe, args.k)
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        out["cpu_baseline"] = {"value": ncpu / ts[1], "unit": "queries/s", "cores": pyoracle.num_threads(),
+                               "kind": "port",
+                               "sample": "%d of the same queries, same index, median of 3 search() calls, "
+                                         "oracle restatement (-O3 -fopenmp), host has %d logical cpus"
+                                         % (ncpu, os.cpu_count())}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,3 +71,33 @@ def assert_same_topk(D, I, Dref, Iref, what=""):
                 loose += 1
             start = end
     return loose
+
+
+def tie_canonical(D, I):
+    """Sort labels inside groups of exactly equal distance (rows are ascending in D)."""
+    out = I.copy()
+    for r in range(D.shape[0]):
+        order = np.lexsort((I[r], D[r]))
+        out[r] = I[r][order]
+    return out
+
+
+def label_agreement(D, I, Dr, Ir):
+    """Fraction of result slots that agree with the reference, where labels inside a
+    group of exactly equal distance are compared as sets and, in the group touching
+    the k-th place, equally distant alternatives count as agreeing."""
+    n, k = D.shape
+    ok = 0
+    for r in range(n):
+        s = 0
+        while s < k:
+            e = s + 1
+            while e < k and Dr[r, e] == Dr[r, s]:
+                e += 1
+            a, b = set(I[r, s:e].tolist()), set(Ir[r, s:e].tolist())
+            if np.array_equal(D[r, s:e], Dr[r, s:e]):
+                ok += (e - s) if (e == k or a == b) else len(a & b)
+            else:
+                ok += len(a & b)
+            s = e
+    return ok / float(n * k)

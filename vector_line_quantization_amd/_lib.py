@@ -1,7 +1,9 @@
 """ctypes loader of csrc/libvlq_ivfpq.so (the C ABI of include/vlq_ivfpq.h)."""
 import ctypes as C
+import importlib.util
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
@@ -40,12 +42,35 @@ def build_library(force=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (SONAME libamdhip64.so.7); if this library were loaded first it would
+    pull the system copy and a later `import torch` would bring a second runtime
+    that cannot open the device.  So when torch is installed but not yet imported,
+    map torch's copy first: our NEEDED libamdhip64.so.7 then binds to it by SONAME."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             raise VlqError(-1, "HIP library %s is not built (run `make -C %s`); there is no "
                                "fallback path" % (_SO, _CSRC))
+        _share_hip_runtime_with_torch()
         L = C.CDLL(_SO)
         L.vlq_last_error.restype = C.c_char_p
         L.vlq_ivfpq_ntotal.restype = C.c_int64
