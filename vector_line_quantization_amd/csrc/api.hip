@@ -87,7 +87,7 @@ struct vlq_ivfpq_s {
 
     // workspace
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
-        ws_cdis_in, ws_codes, ws_assign;
+        ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder;
     DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
     uint64_t stat_nq = 0;
 
@@ -262,7 +262,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.table_mode = table_mode;
         a.max_codes = h->max_codes;
         a.store_pairs = store_pairs;
-        vlq::launch_scan(a, h->stream);
+        const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
+        if (fast16) {
+            if (ni >= 1024) {
+                // run queries that share their nearest centroid next to each other (L2 reuse)
+                TRY(h->ws_hist.reserve(((size_t)h->nlist + 1) * sizeof(int)));
+                TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
+                                        h->ws_qorder.as<int>(), h->stream);
+                a.qorder = h->ws_qorder.as<int>();
+            }
+            vlq::launch_scan16(a, h->stream);
+        } else {
+            vlq::launch_scan(a, h->stream);
+        }
         tm.stop();
     }
     HIP_TRY(hipGetLastError());
@@ -351,7 +364,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->stats};
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats};
     for (auto b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;

@@ -49,8 +49,15 @@ struct ScanArgs {
     int table_mode;              // 0: by_residual, no table; 1: by_residual + term2; 2: not by_residual
     int64_t max_codes;
     int store_pairs;
+    const int* qorder = nullptr; // optional processing order of the queries (scan16 only)
+    int xcd_chunk = 0;           // set by the launcher
 };
 void launch_scan(const ScanArgs& a, hipStream_t s);
+// specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
+void launch_scan16(const ScanArgs& a, hipStream_t s);
+// counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
+void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
+                        int* qorder, hipStream_t s);
 
 // encode path (IndexIVFPQ.cpp:192-231, ProductQuantizer.cpp:311-336)
 void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,

@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "sse_order.cuh"
 #include "wave_topk.cuh"
+#include "scan_common.cuh"
 
 namespace vlq {
 
@@ -467,47 +468,9 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a, int nbuf, int lut
         for (int i = ik; i <= a.nprobe; i++) cum[i] = pos0;
 
     // ---- merge the four waves' selections, emit ----
-    sel.flush();
-    __syncthreads();                       // LUT buffers are free from here on
-    u64* mb = reinterpret_cast<u64*>(smraw);   // [4][k], aliases the LUT
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const int e = r * 64 + lane;
-        if (e < a.k) mb[wave * a.k + e] = sel.best[r];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < 4; w++)
-        for (int e0 = 0; e0 < a.k; e0 += 64) {
-            const int e = e0 + lane;
-            const bool valid = e < a.k;
-            const u64 key = valid ? mb[w * a.k + e] : kMaxKey;
-            sel.offer_key(key, valid);
-        }
-    sel.flush();
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const int e = r * 64 + lane;
-        if (e >= a.k) continue;
-        const u64 key = sel.best[r];
-        float dis = FLT_MAX_F;
-        int64_t id = -1;
-        if (key != kMaxKey) {
-            dis = ordered_to_f32((uint32_t)(key >> 32));
-            const uint32_t pos = (uint32_t)key;
-            int lo = 0, hi = a.nprobe;      // find probe p with cum[p] <= pos < cum[p+1]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (cum[mid] <= pos) lo = mid; else hi = mid;
-            }
-            const int64_t lkey = kq[lo];
-            const int64_t o = pos - cum[lo];
-            id = a.store_pairs ? (lkey << 32 | o) : a.ids[a.list_off[lkey] + o];
-        }
-        a.D[q * a.k + e] = dis;
-        a.I[q * a.k + e] = id;
-    }
-    if (lane == 0) {
+    merge_and_emit<KPL>(sel, smraw, cum, a, q, wave, lane,
+                        [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = a.list_off[lkey]; });
+    if (t == 0) {
         atomicAdd(a.ncode, (unsigned long long)nscan);
         if (badkey) *a.bad_key = 1;
     }
@@ -537,16 +500,9 @@ void launch_scan(const ScanArgs& a, hipStream_t s) {
     lutb = (lutb + 15) & ~(size_t)15;
     const int lut_region = (int)lutb;
     const size_t smem = lutb + tail;
-    const bool fast = a.table_mode == 1 && a.M == 16 && a.ksub == 256 && nbuf == 2;
-    if (fast) {
-        if (a.k <= 64) launch_scan_t<1, true>(a, nbuf, lut_region, smem, s);
-        else if (a.k <= 256) launch_scan_t<4, true>(a, nbuf, lut_region, smem, s);
-        else launch_scan_t<16, true>(a, nbuf, lut_region, smem, s);
-    } else {
-        if (a.k <= 64) launch_scan_t<1, false>(a, nbuf, lut_region, smem, s);
-        else if (a.k <= 256) launch_scan_t<4, false>(a, nbuf, lut_region, smem, s);
-        else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
-    }
+    if (a.k <= 64) launch_scan_t<1, false>(a, nbuf, lut_region, smem, s);
+    else if (a.k <= 256) launch_scan_t<4, false>(a, nbuf, lut_region, smem, s);
+    else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
 }
 
 // ---------------------------------------------------------------------------
