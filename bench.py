@@ -257,6 +257,11 @@ def main():
 
     if not args.no_cpu_baseline:
         from oracle import pyoracle
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count()
+        pyoracle.set_num_threads(cores)      # the threads actually used = the cpus this process may run on
         ncpu = min(args.cpu_queries, args.nq)
         ox.search(xq_h[:min(ncpu, 1000)], args.nprobe, args.k)     # warm-up
         ts = []
@@ -268,8 +273,9 @@ def main():
         out["cpu_baseline"] = {"value": ncpu / ts[1], "unit": "queries/s", "cores": pyoracle.num_threads(),
                                "kind": "port",
                                "sample": "%d of the same queries, same index, median of 3 search() calls, "
-                                         "oracle restatement (-O3 -fopenmp), host has %d logical cpus"
-                                         % (ncpu, os.cpu_count())}
+                                         "oracle restatement (-O3 -fopenmp, %d OpenMP threads = cpus in this "
+                                         "process's affinity mask; host has %d logical cpus)"
+                                         % (ncpu, pyoracle.num_threads(), os.cpu_count())}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

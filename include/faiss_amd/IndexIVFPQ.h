@@ -1,0 +1,193 @@
+// faiss::IndexIVFPQ (IndexIVFPQ.h:29-164) over the MI355X library: same public data
+// model (ids / codes per list, pq, precomputed_table, search-time fields), add()
+// and search() run on the device through the C ABI.  The host-side lists stay the
+// authoritative copy -- exactly what copyFrom / write_index consumers read -- and are
+// mirrored to HBM list-contiguously before the first search after a change.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "IndexFlat.h"
+#include "IndexIVF.h"
+#include "ProductQuantizer.h"
+
+namespace faiss {
+
+struct IndexIVFPQStats {   // IndexIVFPQ.h:169-195
+  size_t nq, nlist, ncode, nrefine, n_hamming_pass;
+  size_t assign_cycles, search_cycles, refine_cycles;
+  size_t init_query_cycles, init_list_cycles, scan_cycles, heap_cycles;
+  IndexIVFPQStats() { reset(); }
+  void reset() { memset(this, 0, sizeof(*this)); }
+};
+inline IndexIVFPQStats indexIVFPQ_stats;   // "global var that collects them all" (IndexIVFPQ.h:195); C++17
+
+struct IndexIVFPQ : IndexIVF {
+  bool by_residual;
+  int use_precomputed_table;
+  size_t code_size;
+  ProductQuantizer pq;
+  bool do_polysemous_training;
+  void* polysemous_training;       // unused: polysemous_ht != 0 is outside the path
+  size_t scan_table_threshold;
+  size_t max_codes;
+  int polysemous_ht;
+  std::vector<std::vector<uint8_t> > codes;
+  std::vector<float> precomputed_table;
+
+  /// device the index lives on (set before train/add/search)
+  int device = 0;
+
+  IndexIVFPQ(Index* quantizer, size_t d, size_t nlist, size_t M, size_t nbits_per_idx)
+      : IndexIVF(quantizer, d, nlist, METRIC_L2), pq(d, M, nbits_per_idx) {
+    FAISS_THROW_IF_NOT(nbits_per_idx <= 8);   // IndexIVFPQ.cpp:51
+    code_size = pq.code_size;
+    is_trained = false;
+    codes.resize(nlist);
+    by_residual = true;
+    use_precomputed_table = 0;
+    scan_table_threshold = 0;
+    max_codes = 0;
+    polysemous_training = nullptr;
+    do_polysemous_training = false;
+    polysemous_ht = 0;
+  }
+  ~IndexIVFPQ() override { if (h_) vlq_ivfpq_destroy(h_); }
+  IndexIVFPQ(const IndexIVFPQ&) = delete;
+  IndexIVFPQ& operator=(const IndexIVFPQ&) = delete;
+
+  /// train_residual_o (IndexIVFPQ.cpp:73-132)
+  void train_residual(idx_t n, const float* x) override {
+    size_t ns = n;
+    std::vector<float> xs = maybe_subsample(d, &ns, pq.cp.max_points_per_centroid * pq.ksub, x, pq.cp.seed);
+    std::vector<float> trainset;
+    if (by_residual) {
+      std::vector<idx_t> assign(ns);
+      quantizer->assign(ns, xs.data(), assign.data());
+      trainset.resize(ns * d);
+      for (size_t i = 0; i < ns; i++) quantizer->compute_residual(&xs[i * d], &trainset[i * d], assign[i]);
+    } else {
+      trainset.swap(xs);
+    }
+    pq.verbose = verbose;
+    pq.train((int)ns, trainset.data());
+    FAISS_THROW_IF_NOT_MSG(!do_polysemous_training, "polysemous training is outside the built path");
+    hdirty_ = true;
+    if (by_residual) precompute_table();
+  }
+
+  /// precompute_table (IndexIVFPQ.cpp:392-459), flat-L2 quantizer: table type 1,
+  /// computed on the device and mirrored into `precomputed_table`
+  void precompute_table() {
+    if (use_precomputed_table == 0) use_precomputed_table = 1;
+    FAISS_THROW_IF_NOT_MSG(use_precomputed_table == 1, "table type 2 (IMI) is not built");
+    sync_(false);
+    precomputed_table.resize(nlist * pq.M * pq.ksub);
+    VLQ_CHECK(vlq_ivfpq_get_precomputed_table(h_, precomputed_table.data()));
+  }
+
+  void add_with_ids(idx_t n, const float* x, const long* xids) override { add_core_o(n, x, xids, nullptr); }
+
+  /// add_core_o (IndexIVFPQ.cpp:192-272): assignment + encoding on the device,
+  /// append to the host lists in input order
+  void add_core_o(idx_t n, const float* x, const long* xids, float* residuals_2,
+                  const long* precomputed_idx = nullptr) {
+    FAISS_THROW_IF_NOT(is_trained);
+    FAISS_THROW_IF_NOT_MSG(!residuals_2 && !precomputed_idx, "IVFPQR / precomputed_idx are outside the built path");
+    if (n == 0) return;
+    sync_(false);
+    std::vector<int64_t> idx(n);
+    std::vector<uint8_t> xcodes((size_t)n * code_size);
+    VLQ_CHECK(vlq_ivfpq_encode(h_, n, x, idx.data(), xcodes.data()));
+    for (idx_t i = 0; i < n; i++) {
+      const int64_t key = idx[i];
+      if (key < 0) continue;
+      ids[key].push_back(xids ? xids[i] : ntotal + i);
+      codes[key].insert(codes[key].end(), &xcodes[i * code_size], &xcodes[(i + 1) * code_size]);
+      if (maintain_direct_map) direct_map.push_back(key << 32 | (long)(ids[key].size() - 1));
+    }
+    ntotal += n;
+    ldirty_ = true;
+  }
+
+  void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override {
+    check_search_();
+    sync_(true);
+    VLQ_CHECK(vlq_ivfpq_search(h_, n, x, (int)nprobe, (int)k, distances, (int64_t*)labels));
+    collect_stats_(n);
+  }
+
+  /// the parity seam (IndexIVFPQ.h:140-146)
+  virtual void search_knn_with_key(size_t nx, const float* qx, const long* keys, const float* coarse_dis,
+                                   float_maxheap_array_t* res, bool store_pairs = false) const {
+    check_search_();
+    sync_(true);
+    VLQ_CHECK(vlq_ivfpq_search_preassigned(h_, (int64_t)nx, qx, (const int64_t*)keys, coarse_dis, (int)nprobe,
+                                           (int)res->k, res->val, (int64_t*)res->ids, store_pairs ? 1 : 0));
+    collect_stats_(nx);
+  }
+
+  void reset() override {
+    IndexIVF::reset();
+    for (auto& c : codes) c.clear();
+    ldirty_ = true;
+  }
+  void reconstruct(idx_t key, float* recons) const override {
+    FAISS_THROW_IF_NOT(maintain_direct_map && key >= 0 && key < (idx_t)direct_map.size());
+    const long list_no = direct_map[key] >> 32, offset = direct_map[key] & 0xffffffff;
+    quantizer->reconstruct(list_no, recons);
+    std::vector<float> r(d);
+    pq.decode(&codes[list_no][offset * code_size], r.data());
+    for (int i = 0; i < d; i++) recons[i] = by_residual ? recons[i] + r[i] : r[i];
+  }
+
+  /// handle of the device copy (GpuIndexIVFPQ::copyFrom reads the host fields instead)
+  vlq_ivfpq_t device_handle() const { sync_(true); return h_; }
+
+ private:
+  void check_search_() const {
+    FAISS_THROW_IF_NOT(is_trained);
+    FAISS_THROW_IF_NOT_MSG(polysemous_ht == 0 && scan_table_threshold == 0,
+                           "polysemous / on-the-fly scan modes are outside the built path");
+  }
+  void collect_stats_(size_t n) const {
+    uint64_t nq = 0, ncode = 0;
+    VLQ_CHECK(vlq_ivfpq_stats(h_, &nq, &ncode, 1));   // also raises on an invalid key (IndexIVFPQ.cpp:1008-1011)
+    indexIVFPQ_stats.nq += n;
+    indexIVFPQ_stats.ncode += ncode;
+  }
+  void sync_(bool with_lists) const {
+    const IndexFlat* flat = dynamic_cast<const IndexFlat*>(quantizer);
+    FAISS_THROW_IF_NOT_MSG(flat && flat->metric_type == METRIC_L2,
+                           "only an IndexFlatL2 coarse quantizer is built (as GpuIndexIVF::copyFrom, gpu/GpuIndexIVF.cu:131-133)");
+    if (!h_) {
+      VLQ_CHECK(vlq_ivfpq_create(&h_, device, d, (int)nlist, (int)pq.M, (int)pq.nbits));
+      hdirty_ = ldirty_ = true;
+    }
+    if (hdirty_) {
+      FAISS_THROW_IF_NOT(flat->ntotal == (idx_t)nlist);
+      VLQ_CHECK(vlq_ivfpq_set_coarse_centroids(h_, flat->xb.data()));
+      VLQ_CHECK(vlq_ivfpq_set_pq_centroids(h_, pq.centroids.data()));
+      hdirty_ = false;
+    }
+    VLQ_CHECK(vlq_ivfpq_set_search_options(h_, by_residual, by_residual ? (use_precomputed_table ? 1 : 0) : 0,
+                                           (int64_t)max_codes));
+    if (with_lists && ldirty_) {
+      std::vector<int64_t> off(nlist + 1, 0);
+      for (size_t i = 0; i < nlist; i++) off[i + 1] = off[i] + (int64_t)ids[i].size();
+      std::vector<uint8_t> fc((size_t)off[nlist] * code_size);
+      std::vector<int64_t> fi((size_t)off[nlist]);
+      for (size_t i = 0; i < nlist; i++) {
+        if (ids[i].empty()) continue;
+        memcpy(&fc[(size_t)off[i] * code_size], codes[i].data(), codes[i].size());
+        for (size_t j = 0; j < ids[i].size(); j++) fi[off[i] + j] = ids[i][j];
+      }
+      VLQ_CHECK(vlq_ivfpq_set_lists(h_, fc.data(), fi.data(), off.data()));
+      ldirty_ = false;
+    }
+  }
+  mutable vlq_ivfpq_t h_ = nullptr;
+  mutable bool hdirty_ = true, ldirty_ = true;
+};
+
+}  // namespace faiss

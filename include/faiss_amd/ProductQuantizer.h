@@ -1,0 +1,52 @@
+// faiss::ProductQuantizer data model (ProductQuantizer.h:25-60) with training by
+// per-sub-quantizer k-means (ProductQuantizer.cpp:236-308, Train_default).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "Clustering.h"
+#include "IndexFlat.h"
+
+namespace faiss {
+
+struct ProductQuantizer {
+  size_t d, M, nbits;
+  size_t dsub, byte_per_idx, code_size, ksub;
+  bool verbose;
+  ClusteringParameters cp;
+  std::vector<float> centroids;   ///< M * ksub * dsub
+
+  ProductQuantizer(size_t d, size_t M, size_t nbits) : d(d), M(M), nbits(nbits) { set_derived_values(); }
+  ProductQuantizer() : d(0), M(1), nbits(0) { set_derived_values(); }
+
+  void set_derived_values() {   // ProductQuantizer.cpp:163-175
+    FAISS_THROW_IF_NOT(M > 0 && d % M == 0);
+    dsub = d / M;
+    byte_per_idx = (nbits + 7) / 8;
+    code_size = byte_per_idx * M;
+    ksub = (size_t)1 << nbits;
+    centroids.resize(d * ksub);
+    verbose = false;
+  }
+  float* get_centroids(size_t m, size_t i) { return &centroids[(m * ksub + i) * dsub]; }
+  const float* get_centroids(size_t m, size_t i) const { return &centroids[(m * ksub + i) * dsub]; }
+
+  void train(int n, const float* x) {
+    std::vector<float> xs((size_t)n * dsub);
+    for (size_t m = 0; m < M; m++) {
+      for (int j = 0; j < n; j++) memcpy(&xs[(size_t)j * dsub], x + (size_t)j * d + m * dsub, dsub * sizeof(float));
+      Clustering clus((int)dsub, (int)ksub, cp);
+      IndexFlatL2 index(dsub);
+      clus.train(n, xs.data(), index);
+      memcpy(get_centroids(m, 0), clus.centroids.data(), ksub * dsub * sizeof(float));
+    }
+  }
+  void decode(const uint8_t* code, float* x) const {
+    for (size_t m = 0; m < M; m++) memcpy(x + m * dsub, get_centroids(m, code[m]), sizeof(float) * dsub);
+  }
+  void decode(const uint8_t* code, float* x, size_t n) const {
+    for (size_t i = 0; i < n; i++) decode(code + M * i, x + d * i);
+  }
+};
+
+}  // namespace faiss

@@ -1,0 +1,234 @@
+// faiss::gpu::GpuIndexIVFPQ construction and search surface
+// (gpu/GpuIndexIVFPQ.h:24-234, gpu/GpuIndexIVF.h:25-95, gpu/GpuIndex.h:19-102,
+// gpu/GpuIndexFlat.h:27-49) over the MI355X library.  The fork's VLQ members
+// (nedge / nLambda constructor, graph files) belong to the VLQ row of SURVEY.md §8f.
+#pragma once
+#include <vector>
+
+#include "compat.h"
+#include "GpuIndicesOptions.h"
+#include "GpuResources.h"
+
+namespace faiss { namespace gpu {
+
+enum class MemorySpace { Device = 1, Unified = 2 };   // gpu/utils/MemorySpace.h
+
+struct GpuIndexConfig {
+  GpuIndexConfig() : device(0), memorySpace(MemorySpace::Device) {}
+  int device;
+  MemorySpace memorySpace;
+};
+struct GpuIndexFlatConfig : public GpuIndexConfig {
+  GpuIndexFlatConfig() : useFloat16(false), useFloat16Accumulator(false), storeTransposed(false) {}
+  bool useFloat16;              ///< must stay false: the path computes in fp32 (parity with the CPU index)
+  bool useFloat16Accumulator;
+  bool storeTransposed;         ///< layout hint of the reference's cuBLAS call; no effect here
+};
+struct GpuIndexIVFConfig : public GpuIndexConfig {
+  GpuIndexIVFConfig() : indicesOptions(INDICES_64_BIT) {}
+  IndicesOptions indicesOptions;
+  GpuIndexFlatConfig flatConfig;
+};
+struct GpuIndexIVFPQConfig : public GpuIndexIVFConfig {
+  GpuIndexIVFPQConfig() : useFloat16LookupTables(false), usePrecomputedTables(false) {}
+  bool useFloat16LookupTables;  ///< must stay false (fp32 LUT, bit parity)
+  bool usePrecomputedTables;
+};
+
+class GpuIndex : public faiss::Index {
+ public:
+  GpuIndex(GpuResources* resources, int dims, faiss::MetricType metric, GpuIndexConfig config)
+      : Index(dims, metric), resources_(resources), device_(config.device), memorySpace_(config.memorySpace) {
+    FAISS_THROW_IF_NOT_MSG(resources_, "null GpuResources");
+    FAISS_THROW_IF_NOT_MSG(metric == METRIC_L2, "only METRIC_L2 is built");
+    resources_->initializeForDevice(device_);
+  }
+  int getDevice() const { return device_; }
+  GpuResources* getResources() { return resources_; }
+
+ protected:
+  GpuResources* resources_;
+  const int device_;
+  const MemorySpace memorySpace_;
+};
+
+class GpuIndexIVFPQ : public GpuIndex {
+ public:
+  /// copy-construct from a trained CPU index (gpu/GpuIndexIVFPQ.h:45-49)
+  GpuIndexIVFPQ(GpuResources* resources, const faiss::IndexIVFPQ* index,
+                GpuIndexIVFPQConfig config = GpuIndexIVFPQConfig())
+      : GpuIndex(resources, index->d, index->metric_type, config), ivfpqConfig_(config),
+        nlist_((int)index->nlist), nprobe_(1), subQuantizers_(0), bitsPerCode_(0), reserveMemoryVecs_(0) {
+    verifyConfig_();
+    copyFrom(index);
+  }
+  /// empty index (gpu/GpuIndexIVFPQ.h:52-58)
+  GpuIndexIVFPQ(GpuResources* resources, int dims, int nlist, int subQuantizers, int bitsPerCode,
+                faiss::MetricType metric, GpuIndexIVFPQConfig config = GpuIndexIVFPQConfig())
+      : GpuIndex(resources, dims, metric, config), ivfpqConfig_(config), nlist_(nlist), nprobe_(1),
+        subQuantizers_(subQuantizers), bitsPerCode_(bitsPerCode), reserveMemoryVecs_(0) {
+    verifyConfig_();
+    FAISS_THROW_IF_NOT_MSG(bitsPerCode_ >= 1 && bitsPerCode_ <= 8, "Bits per code must be <= 8");
+    FAISS_THROW_IF_NOT_MSG(dims % subQuantizers_ == 0, "Number of sub-quantizers must be an even divisor of the dimensions");
+    is_trained = false;
+    create_();
+  }
+  ~GpuIndexIVFPQ() override { if (h_) vlq_ivfpq_destroy(h_); }
+  GpuIndexIVFPQ(const GpuIndexIVFPQ&) = delete;
+  GpuIndexIVFPQ& operator=(const GpuIndexIVFPQ&) = delete;
+
+  /// gpu/GpuIndexIVFPQ.cu:168-231
+  void copyFrom(const faiss::IndexIVFPQ* index) {
+    FAISS_THROW_IF_NOT_MSG(index->pq.byte_per_idx == 1, "GPU: only pq.byte_per_idx == 1 is supported");
+    FAISS_THROW_IF_NOT_MSG(index->by_residual, "GPU: only by_residual = true is supported");
+    FAISS_THROW_IF_NOT_MSG(index->polysemous_ht == 0, "GPU: polysemous codes not supported");
+    const IndexFlat* flat = dynamic_cast<const IndexFlat*>(index->quantizer);
+    FAISS_THROW_IF_NOT_MSG(flat && flat->metric_type == METRIC_L2,
+                           "Only IndexFlatL2 is supported as the coarse quantizer (gpu/GpuIndexIVF.cu:131-133)");
+    d = index->d; metric_type = index->metric_type;
+    nlist_ = (int)index->nlist; nprobe_ = (int)index->nprobe;
+    subQuantizers_ = (int)index->pq.M; bitsPerCode_ = (int)index->pq.nbits;
+    if (h_) { vlq_ivfpq_destroy(h_); h_ = nullptr; }
+    create_();
+    is_trained = index->is_trained;
+    ntotal = 0;
+    if (!index->is_trained) return;
+    FAISS_THROW_IF_NOT(flat->ntotal == (idx_t)index->nlist);
+    coarse_ = flat->xb;
+    pqCentroids_ = index->pq.centroids;
+    VLQ_CHECK(vlq_ivfpq_set_coarse_centroids(h_, coarse_.data()));
+    VLQ_CHECK(vlq_ivfpq_set_pq_centroids(h_, pqCentroids_.data()));
+    usePrecomputed_ = ivfpqConfig_.usePrecomputedTables || index->use_precomputed_table == 1;
+    VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, usePrecomputed_ ? 1 : 0, (int64_t)index->max_codes));
+    std::vector<int64_t> off(nlist_ + 1, 0);
+    for (int i = 0; i < nlist_; i++) off[i + 1] = off[i] + (int64_t)index->ids[i].size();
+    std::vector<uint8_t> fc((size_t)off[nlist_] * subQuantizers_);
+    std::vector<int64_t> fi((size_t)off[nlist_]);
+    for (int i = 0; i < nlist_; i++) {
+      if (index->ids[i].empty()) continue;
+      memcpy(&fc[(size_t)off[i] * subQuantizers_], index->codes[i].data(), index->codes[i].size());
+      for (size_t j = 0; j < index->ids[i].size(); j++) fi[off[i] + j] = index->ids[i][j];
+    }
+    VLQ_CHECK(vlq_ivfpq_set_lists(h_, fc.data(), fi.data(), off.data()));
+    ntotal = index->ntotal;
+  }
+
+  /// gpu/GpuIndexIVFPQ.cu:233-290: overwrite a CPU index with our state
+  void copyTo(faiss::IndexIVFPQ* index) const {
+    FAISS_THROW_IF_NOT_MSG(ivfpqConfig_.indicesOptions != INDICES_IVF, "Cannot copy to CPU as GPU index doesn't retain indices (INDICES_IVF)");
+    IndexFlat* flat = dynamic_cast<IndexFlat*>(index->quantizer);
+    FAISS_THROW_IF_NOT_MSG(flat, "target quantizer must be an IndexFlat");
+    index->d = d; index->metric_type = metric_type; index->is_trained = is_trained;
+    index->nlist = nlist_; index->nprobe = nprobe_; index->ntotal = ntotal;
+    index->by_residual = true; index->use_precomputed_table = 0;
+    index->pq = faiss::ProductQuantizer(d, subQuantizers_, bitsPerCode_);
+    index->code_size = subQuantizers_;
+    index->ids.assign(nlist_, std::vector<long>());
+    index->codes.assign(nlist_, std::vector<uint8_t>());
+    flat->reset();
+    if (!is_trained) return;
+    flat->add(nlist_, coarse_.data());
+    index->pq.centroids = pqCentroids_;
+    for (int i = 0; i < nlist_; i++) {
+      index->ids[i] = getListIndices(i);
+      index->codes[i] = getListCodes(i);
+    }
+    if (usePrecomputed_) index->precompute_table();
+  }
+
+  void reserveMemory(size_t numVecs) { reserveMemoryVecs_ = numVecs; }
+  size_t reclaimMemory() { return 0; }   // lists are stored exactly sized already
+  void setPrecomputedCodes(bool enable) {
+    usePrecomputed_ = enable;
+    VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, enable ? 1 : 0, 0));
+  }
+  bool getPrecomputedCodes() const { return usePrecomputed_; }
+  int getNumSubQuantizers() const { return subQuantizers_; }
+  int getBitsPerCode() const { return bitsPerCode_; }
+  int getCentroidsPerSubQuantizer() const { return 1 << bitsPerCode_; }
+  int getNumLists() const { return nlist_; }
+  /// gpu/GpuIndexIVF.cu:201-207
+  void setNumProbes(int nprobe) {
+    FAISS_THROW_IF_NOT_MSG(nprobe > 0 && nprobe <= VLQ_MAX_NPROBE, "nprobe must be in 1..1024");
+    nprobe_ = nprobe;
+  }
+  int getNumProbes() const { return nprobe_; }
+
+  void reset() override {
+    std::vector<int64_t> off(nlist_ + 1, 0);
+    VLQ_CHECK(vlq_ivfpq_set_lists(h_, nullptr, nullptr, off.data()));
+    ntotal = 0;
+  }
+
+  /// k-means of the coarse quantizer + PQ on residuals, on the device
+  /// (GpuIndexIVFPQ::train gpu/GpuIndexIVFPQ.cu:1160-1178 minus the fork's graph build)
+  void train(Index::idx_t n, const float* x) override {
+    if (is_trained) return;
+    faiss::IndexFlatL2 flat(d);
+    faiss::IndexIVFPQ cpu(&flat, d, nlist_, subQuantizers_, bitsPerCode_);
+#ifndef VLQ_WITH_REFERENCE_FAISS
+    flat.device = device_;   // our CPU-named classes train on the device too
+    cpu.device = device_;
+#endif
+    cpu.verbose = verbose;
+    cpu.train(n, x);
+    cpu.nprobe = nprobe_;
+    copyFrom(&cpu);
+  }
+  void add(Index::idx_t n, const float* x) override { add_with_ids(n, x, nullptr); }
+  void add_with_ids(Index::idx_t n, const float* x, const Index::idx_t* ids) override {
+    FAISS_THROW_IF_NOT_MSG(is_trained, "Index not trained");
+    VLQ_CHECK(vlq_ivfpq_add(h_, n, x, (const int64_t*)ids));
+    ntotal += n;
+  }
+  void search(Index::idx_t n, const float* x, Index::idx_t k, float* distances, Index::idx_t* labels) const override {
+    FAISS_THROW_IF_NOT_MSG(is_trained, "Index not trained");
+    FAISS_THROW_IF_NOT_MSG(k >= 1 && k <= VLQ_MAX_K, "k outside 1..1024 (gpu/impl/IVFPQ.cu:966-967)");
+    if (ivfpqConfig_.indicesOptions == INDICES_IVF) {
+      std::vector<int64_t> keys((size_t)n * nprobe_);
+      std::vector<float> cd((size_t)n * nprobe_);
+      VLQ_CHECK(vlq_ivfpq_coarse_search(h_, n, x, nprobe_, cd.data(), keys.data()));
+      VLQ_CHECK(vlq_ivfpq_search_preassigned(h_, n, x, keys.data(), cd.data(), nprobe_, (int)k, distances,
+                                             (int64_t*)labels, 1));
+    } else {
+      VLQ_CHECK(vlq_ivfpq_search(h_, n, x, nprobe_, (int)k, distances, (int64_t*)labels));
+    }
+  }
+
+  int getListLength(int listId) const {
+    int64_t len = 0;
+    VLQ_CHECK(vlq_ivfpq_list_length(h_, listId, &len));
+    return (int)len;
+  }
+  std::vector<unsigned char> getListCodes(int listId) const {
+    std::vector<unsigned char> c((size_t)getListLength(listId) * subQuantizers_);
+    VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, c.data(), nullptr));
+    return c;
+  }
+  std::vector<long> getListIndices(int listId) const {
+    std::vector<int64_t> v((size_t)getListLength(listId));
+    VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, nullptr, v.data()));
+    return std::vector<long>(v.begin(), v.end());
+  }
+  vlq_ivfpq_t handle() const { return h_; }
+
+ private:
+  void verifyConfig_() const {
+    FAISS_THROW_IF_NOT_MSG(!ivfpqConfig_.useFloat16LookupTables && !ivfpqConfig_.flatConfig.useFloat16,
+                           "float16 tables/storage are not built: the path is fp32 for bit parity with the CPU index");
+  }
+  void create_() {
+    VLQ_CHECK(vlq_ivfpq_create(&h_, device_, d, nlist_, subQuantizers_, bitsPerCode_));
+    VLQ_CHECK(vlq_ivfpq_set_stream(h_, (void*)resources_->getDefaultStream(device_)));
+    usePrecomputed_ = ivfpqConfig_.usePrecomputedTables;
+    VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, usePrecomputed_ ? 1 : 0, 0));
+  }
+  GpuIndexIVFPQConfig ivfpqConfig_;
+  int nlist_, nprobe_, subQuantizers_, bitsPerCode_;
+  size_t reserveMemoryVecs_;
+  bool usePrecomputed_ = false;
+  std::vector<float> coarse_, pqCentroids_;
+  vlq_ivfpq_t h_ = nullptr;
+};
+
+} }

@@ -429,6 +429,14 @@ void orc_heap_topk(const float* vals, const int64_t* ids, size_t n, size_t k, fl
     maxheap_reorder(k, D, I);
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -221,3 +221,7 @@ def fvec_norm_L2sqr(x):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))

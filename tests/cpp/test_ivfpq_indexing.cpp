@@ -1,0 +1,106 @@
+// C++ parity test of the faiss-compatible shell (include/faiss_amd) on an MI355X.
+// Part 1 follows the reference's own unit test tests/test_ivfpq_indexing.cpp:20-100
+// (same shapes, same drand48 stream, same acceptance bar n_ok > 0.4 * nq); part 2
+// follows the shape of gpu/test/TestGpuIndexIVFPQ.cpp (GPU index built from a CPU
+// index must answer like it -- here: identically); part 3 checks error behaviour.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "faiss_amd/IndexFlat.h"
+#include "faiss_amd/IndexIVFPQ.h"
+#include "faiss_amd/gpu/GpuIndexIVFPQ.h"
+#include "faiss_amd/gpu/StandardGpuResources.h"
+
+#define EXPECT(c) do { if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
+
+int main() {
+  int failures = 0;
+  const int d = 64;
+  const size_t nb = 1000, nt = 1500;
+  const int ncentroids = 25, nq = 200, k = 5;
+
+  faiss::IndexFlatL2 coarse_quantizer(d);
+  faiss::IndexIVFPQ index(&coarse_quantizer, d, ncentroids, 16, 8);
+  faiss::IndexFlatL2 index_gt(d);
+
+  srand48(35);
+  std::vector<float> trainvecs(nt * d), database(nb * d), queries((size_t)nq * d);
+  for (auto& v : trainvecs) v = drand48();
+  index.train(nt, trainvecs.data());
+  for (auto& v : database) v = drand48();
+  index.add(nb, database.data());
+  index_gt.add(nb, database.data());
+  for (auto& v : queries) v = drand48();
+
+  std::vector<faiss::Index::idx_t> gt_nns(nq), nns((size_t)k * nq);
+  std::vector<float> gt_dis(nq), dis((size_t)k * nq);
+  index_gt.search(nq, queries.data(), 1, gt_dis.data(), gt_nns.data());
+  index.nprobe = 5;
+  index.search(nq, queries.data(), k, dis.data(), nns.data());
+  int n_ok = 0;
+  for (int q = 0; q < nq; q++)
+    for (int i = 0; i < k; i++)
+      if (nns[q * k + i] == gt_nns[q]) n_ok++;
+  printf("part 1: n_ok = %d of %d (bar %d), ntotal=%ld, use_precomputed_table=%d, imbalance=%.2f\n", n_ok, nq,
+         (int)(nq * 0.4), index.ntotal, index.use_precomputed_table, index.imbalance_factor());
+  EXPECT(n_ok > nq * 0.4);
+  EXPECT(index.use_precomputed_table == 1);                       // IndexIVFPQ.cpp:128-130,396-408
+  EXPECT(index.precomputed_table.size() == (size_t)ncentroids * 16 * 256);
+  EXPECT(faiss::indexIVFPQ_stats.nq == (size_t)nq && faiss::indexIVFPQ_stats.ncode > 0);
+
+  // part 2: GPU index copied from the CPU-side object answers identically
+  faiss::gpu::StandardGpuResources res;
+  faiss::gpu::GpuIndexIVFPQConfig config;
+  config.usePrecomputedTables = true;
+  faiss::gpu::GpuIndexIVFPQ gpuIndex(&res, &index, config);
+  gpuIndex.setNumProbes(5);
+  std::vector<faiss::Index::idx_t> gnns((size_t)k * nq);
+  std::vector<float> gdis((size_t)k * nq);
+  gpuIndex.search(nq, queries.data(), k, gdis.data(), gnns.data());
+  EXPECT(gnns == nns);
+  EXPECT(gdis == dis);
+  EXPECT(gpuIndex.ntotal == (faiss::Index::idx_t)nb && gpuIndex.getNumLists() == ncentroids);
+  EXPECT(gpuIndex.getNumSubQuantizers() == 16 && gpuIndex.getBitsPerCode() == 8 &&
+         gpuIndex.getCentroidsPerSubQuantizer() == 256);
+  for (int l = 0; l < ncentroids; l++) {
+    EXPECT(gpuIndex.getListLength(l) == (int)index.ids[l].size());
+    EXPECT(gpuIndex.getListIndices(l) == index.ids[l]);
+    EXPECT(gpuIndex.getListCodes(l) == index.codes[l]);
+  }
+  // copyTo round trip (TestGpuIndexIVFPQ.cpp CopyTo)
+  faiss::IndexFlatL2 q2(d);
+  faiss::IndexIVFPQ back(&q2, d, ncentroids, 16, 8);
+  gpuIndex.copyTo(&back);
+  back.nprobe = 5;
+  std::vector<faiss::Index::idx_t> bnns((size_t)k * nq);
+  std::vector<float> bdis((size_t)k * nq);
+  back.search(nq, queries.data(), k, bdis.data(), bnns.data());
+  EXPECT(bnns == nns && bdis == dis);
+  // an empty GPU index trained and filled on the device
+  faiss::gpu::GpuIndexIVFPQ fresh(&res, d, ncentroids, 16, 8, faiss::METRIC_L2, config);
+  fresh.train(nt, trainvecs.data());
+  fresh.add(nb, database.data());
+  fresh.setNumProbes(5);
+  fresh.search(nq, queries.data(), k, gdis.data(), gnns.data());
+  EXPECT(gnns == nns && gdis == dis);       // same training recipe, same seeds -> same index
+
+  // part 3: error behaviour (FAISS_THROW_* -> FaissException)
+  bool threw = false;
+  try { faiss::IndexIVFPQ bad(&coarse_quantizer, d, ncentroids, 16, 9); } catch (const faiss::FaissException&) { threw = true; }
+  EXPECT(threw);
+  threw = false;
+  try { gpuIndex.setNumProbes(5000); } catch (const faiss::FaissException&) { threw = true; }
+  EXPECT(threw);
+  threw = false;
+  try {   // invalid key through the seam: reference prints "Invalid key" and throws
+    std::vector<long> keys((size_t)nq * 5, 99);
+    std::vector<float> cd((size_t)nq * 5, 0.f);
+    faiss::float_maxheap_array_t r = {(size_t)nq, (size_t)k, nns.data(), dis.data()};
+    index.search_knn_with_key(nq, queries.data(), keys.data(), cd.data(), &r);
+  } catch (const faiss::FaissException&) { threw = true; }
+  EXPECT(threw);
+
+  printf(failures ? "C++ shell test: %d FAILURES\n" : "C++ shell test: all ok\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,53 @@
+"""The faiss-compatible C++ shell (include/faiss_amd): compiles and links on CPU
+against the C-ABI library; on the GPU box the binary replays the reference's own
+unit test (tests/test_ivfpq_indexing.cpp) and a GPU-from-CPU copy test."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "vector_line_quantization_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", CPP])
+    return os.path.join(CPP, "test_ivfpq_indexing")
+
+
+def test_shell_compiles_and_links():
+    exe = _build()
+    assert os.access(exe, os.X_OK)
+
+
+def test_shell_fails_loudly_without_gpu():
+    import vector_line_quantization_amd as vlq
+    if vlq.device_count() > 0:
+        pytest.skip("GPU present")
+    exe = _build()
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode != 0            # uncaught FaissException: no HIP device, no fallback
+    assert "no HIP device" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_shell_on_gpu():
+    exe = _build()
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all ok" in p.stdout
+
+
+def test_gpu_shell_builds_against_reference_headers():
+    """the GPU shell compiles against the REFERENCE's own CPU
+    headers and links with the reference's own CPU library (build container only)."""
+    if not (os.path.isdir("/root/reference") and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
+        pytest.skip("reference tree / oracle/_ref not available here")
+    subprocess.check_call(["make", "-s", "-C", CPP, "link_against_reference"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "oracle/_ref/mkl") + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run(["./link_against_reference"], cwd=CPP, env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "reference CPU index: ntotal=2000 use_precomputed_table=1" in p.stdout

@@ -476,7 +476,8 @@ int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* 
 
 int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe,
                             float* coarse_dis, int64_t* keys) {
-    TRY(check_ready(h, false));
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (!h->have_coarse) return fail(VLQ_ERR_STATE, "coarse centroids not set (index not trained)");
     TRY(check_search_args(h, n, x, nprobe, 1, coarse_dis, keys));
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
