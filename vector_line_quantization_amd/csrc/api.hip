@@ -229,11 +229,14 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
     const size_t E = (size_t)h->M * h->ksub;
     const int table_mode = !h->by_residual ? 2 : (h->use_precomputed_table == 1 ? 1 : 0);
     const int64_t page = 32768;
-    if (table_mode != 0) TRY(h->ws_qtab.reserve((size_t)std::min(n, page) * E * sizeof(float)));
+    // M=16 x 8 bit x d=128 in table mode 1: the scan kernel builds the per-query table itself
+    const bool fused_tables = table_mode == 1 && h->M == 16 && h->ksub == 256 && h->dsub == 8;
+    if (table_mode != 0 && !fused_tables)
+        TRY(h->ws_qtab.reserve((size_t)std::min(n, page) * E * sizeof(float)));
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
         const float* xi = x_dev + i0 * h->d;
-        if (table_mode != 0) {
+        if (table_mode != 0 && !fused_tables) {
             StageTimer tm(h, 1);
             // init_query_L2 (IndexIVFPQ.cpp:557-563): ip table (mode 1) or distance table
             vlq::launch_pq_tables(xi, ni, h->d, h->pq.as<float>(), h->M, h->ksub, h->dsub, nullptr,
@@ -246,7 +249,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.ids = h->ids.as<int64_t>();
         a.list_off = h->list_off.as<int64_t>();
         a.term2 = table_mode == 1 ? h->term2.as<float>() : nullptr;
-        a.qtab = table_mode != 0 ? h->ws_qtab.as<float>() : nullptr;
+        a.qtab = (table_mode != 0 && !fused_tables) ? h->ws_qtab.as<float>() : nullptr;
         a.queries = xi;
         a.coarse = h->coarse.as<float>();
         a.pq_cent = h->pq.as<float>();

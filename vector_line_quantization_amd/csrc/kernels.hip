@@ -202,11 +202,30 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
     WaveSelect<KPL> sel;
     sel.init(nprobe, queue[wave], lane);
     const float* row = dist + q * nlist;
-    for (int j0 = 0; j0 < nlist; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < nlist;
-        const float v = valid ? row[j] : 0.f;
-        sel.offer(v, (uint32_t)j, valid);
+    if ((nlist & 3) == 0) {
+        // 16 B per lane, next 1 KiB of the row requested before the current one is consumed
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        const int n4 = nlist >> 2;
+        float4 cur = lane < n4 ? row4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = 0; j0 < n4; j0 += 64) {
+            const int j4 = j0 + lane;
+            const int jn = j4 + 64;
+            float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jn < n4) nxt = row4[jn];
+            const bool valid = j4 < n4;
+            sel.offer(cur.x, (uint32_t)(4 * j4 + 0), valid);
+            sel.offer(cur.y, (uint32_t)(4 * j4 + 1), valid);
+            sel.offer(cur.z, (uint32_t)(4 * j4 + 2), valid);
+            sel.offer(cur.w, (uint32_t)(4 * j4 + 3), valid);
+            cur = nxt;
+        }
+    } else {
+        for (int j0 = 0; j0 < nlist; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < nlist;
+            const float v = valid ? row[j] : 0.f;
+            sel.offer(v, (uint32_t)j, valid);
+        }
     }
     sel.flush();
 #pragma unroll

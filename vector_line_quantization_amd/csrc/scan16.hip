@@ -56,15 +56,40 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
         pkey[p] = (live && len > 0) ? (int32_t)key : -1;   // empty lists are skipped (:1016)
         pd0[p] = cq[p];
     }
-    // -2 * sim_table_2 of this query, 16 entries per thread, kept for all probes
+    // -2 * sim_table_2 of this query (ProductQuantizer::compute_inner_prod_table,
+    // ProductQuantizer.cpp:424-436), 16 entries per thread, kept in registers for all
+    // probes.  Entry e = 4*(i*256+t)+c  ->  sub-quantizer m = 4i + wave (wave-uniform),
+    // centroid j = 4*lane + c: the four centroids of a thread are 128 contiguous bytes
+    // of the L2-resident 128 KB codebook, the query sub-vector is a scalar load.
     float4 m2t3[4];
-    {
+    if (a.qtab) {
         const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float4 v = qt[i * 256 + t];
             m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
                                   __fmul_rn(-2.f, v.w));
+        }
+    } else {
+        const float* qv = a.queries + q * 128;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = 4 * i + wave;
+            const float4* cp4 = reinterpret_cast<const float4*>(a.pq_cent + ((size_t)m * 256 + lane * 4) * 8);
+            const float4 x0 = *reinterpret_cast<const float4*>(qv + m * 8);
+            const float4 x1 = *reinterpret_cast<const float4*>(qv + m * 8 + 4);
+            float r[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float4 y0 = cp4[2 * c], y1 = cp4[2 * c + 1];
+                // fvec_inner_product, d = 8 (utils.cpp:509-533): lanes (0+x0y0)+x4y4 ..., +0 tail, hadd
+                const float s0 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.x, y0.x)), __fmul_rn(x1.x, y1.x)), 0.f);
+                const float s1 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.y, y0.y)), __fmul_rn(x1.y, y1.y)), 0.f);
+                const float s2 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.z, y0.z)), __fmul_rn(x1.z, y1.z)), 0.f);
+                const float s3 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.w, y0.w)), __fmul_rn(x1.w, y1.w)), 0.f);
+                r[c] = __fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)));
+            }
+            m2t3[i] = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
     __syncthreads();
