@@ -261,9 +261,19 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except AttributeError:
             cores = os.cpu_count()
-        pyoracle.set_num_threads(cores)      # the threads actually used = the cpus this process may run on
         ncpu = min(args.cpu_queries, args.nq)
-        ox.search(xq_h[:min(ncpu, 1000)], args.nprobe, args.k)     # warm-up
+        # pick the OpenMP thread count that serves the CPU best on this box (the affinity mask
+        # can be wider than the container's cpu share)
+        best_t, best_dt = 1, float("inf")
+        for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)}):
+            pyoracle.set_num_threads(nt)
+            ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
+            t1 = time.perf_counter()
+            ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
+            dt = time.perf_counter() - t1
+            if dt < best_dt:
+                best_t, best_dt = nt, dt
+        pyoracle.set_num_threads(best_t)
         ts = []
         for _ in range(3):
             t1 = time.perf_counter()
@@ -273,9 +283,9 @@ def main():
         out["cpu_baseline"] = {"value": ncpu / ts[1], "unit": "queries/s", "cores": pyoracle.num_threads(),
                                "kind": "port",
                                "sample": "%d of the same queries, same index, median of 3 search() calls, "
-                                         "oracle restatement (-O3 -fopenmp, %d OpenMP threads = cpus in this "
-                                         "process's affinity mask; host has %d logical cpus)"
-                                         % (ncpu, pyoracle.num_threads(), os.cpu_count())}
+                                         "oracle restatement (-O3 -fopenmp, %d OpenMP threads = fastest of "
+                                         "8..%d tried; affinity mask %d cpus, host %d logical cpus)"
+                                         % (ncpu, pyoracle.num_threads(), cores, cores, os.cpu_count())}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -81,7 +81,7 @@ struct vlq_ivfpq_s {
     int64_t ntotal = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
 
-    DevBuf coarse, cnorm, pq, rnorm, term2, codes, ids, list_off;
+    DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off;
     bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
     std::vector<int64_t> h_list_off;
 
@@ -253,6 +253,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.queries = xi;
         a.coarse = h->coarse.as<float>();
         a.pq_cent = h->pq.as<float>();
+        a.pq_cent_t = h->pq_t.as<float>();
         a.keys = keys_dev + i0 * nprobe;
         a.coarse_dis = cdis_dev + i0 * nprobe;
         a.D = D_dev + i0 * k;
@@ -364,7 +365,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     (void)hipStreamSynchronize(h->stream);
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->rnorm, &h->term2, &h->codes, &h->ids,
+    DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats};
@@ -407,6 +408,8 @@ int vlq_ivfpq_set_pq_centroids(vlq_ivfpq_t h, const float* centroids) {
     HIP_TRY(hipMemcpyAsync(h->pq.p, centroids, bytes, hipMemcpyDefault, h->stream));
     // r_norms (IndexIVFPQ.cpp:411-416)
     vlq::launch_row_norms(h->pq.as<float>(), (int64_t)n, h->dsub, h->rnorm.as<float>(), h->stream);
+    TRY(h->pq_t.reserve(bytes));
+    vlq::launch_transpose_pq(h->pq.as<float>(), h->M, h->ksub, h->dsub, h->pq_t.as<float>(), h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_pq = true;

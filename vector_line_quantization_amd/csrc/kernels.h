@@ -38,6 +38,7 @@ struct ScanArgs {
     const float* queries;        // [nq][d]          (table mode 0 only)
     const float* coarse;         // [nlist][d]       (table mode 0 only)
     const float* pq_cent;        // [M][ksub][dsub]  (table mode 0 only)
+    const float* pq_cent_t = nullptr;  // [M][dsub][ksub] transposed copy (scan16 fused tables)
     const int64_t* keys;         // [nq][nprobe]
     const float* coarse_dis;     // [nq][nprobe]
     float* D;                    // [nq][k]
@@ -58,6 +59,9 @@ void launch_scan16(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s);
+
+// out[m][c][j] = in[m][j][c]
+void launch_transpose_pq(const float* in, int M, int ksub, int dsub, float* out, hipStream_t s);
 
 // encode path (IndexIVFPQ.cpp:192-231, ProductQuantizer.cpp:311-336)
 void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,

@@ -524,6 +524,23 @@ void launch_scan(const ScanArgs& a, hipStream_t s) {
     else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
 }
 
+__global__ void transpose_pq_kernel(const float* __restrict__ in, int M, int ksub, int dsub,
+                                    float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)M * ksub * dsub;
+    if (e >= n) return;
+    const int c = (int)(e % dsub);
+    const int j = (int)((e / dsub) % ksub);
+    const int m = (int)(e / ((int64_t)dsub * ksub));
+    out[((int64_t)m * dsub + c) * ksub + j] = in[e];
+}
+
+void launch_transpose_pq(const float* in, int M, int ksub, int dsub, float* out, hipStream_t s) {
+    const int64_t n = (int64_t)M * ksub * dsub;
+    hipLaunchKernelGGL(transpose_pq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, M,
+                       ksub, dsub, out);
+}
+
 // ---------------------------------------------------------------------------
 // encode: residual to the assigned centroid, then per sub-quantizer the first
 // minimum of fvec_L2sqr (ProductQuantizer.cpp:311-336: strict '<', mindis = 1e20).

@@ -71,25 +71,28 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
                                   __fmul_rn(-2.f, v.w));
         }
     } else {
+        // codebook read from its transposed copy pq_cent_t[m][component][j]: the four
+        // centroids j = 4*lane..4*lane+3 of one component are one 16-byte load, a wave
+        // reads 1 KiB contiguous per instruction
         const float* qv = a.queries + q * 128;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = 4 * i + wave;
-            const float4* cp4 = reinterpret_cast<const float4*>(a.pq_cent + ((size_t)m * 256 + lane * 4) * 8);
+            const float4* ct = reinterpret_cast<const float4*>(a.pq_cent_t + (size_t)m * 8 * 256) + lane;
             const float4 x0 = *reinterpret_cast<const float4*>(qv + m * 8);
             const float4 x1 = *reinterpret_cast<const float4*>(qv + m * 8 + 4);
-            float r[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float4 y0 = cp4[2 * c], y1 = cp4[2 * c + 1];
-                // fvec_inner_product, d = 8 (utils.cpp:509-533): lanes (0+x0y0)+x4y4 ..., +0 tail, hadd
-                const float s0 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.x, y0.x)), __fmul_rn(x1.x, y1.x)), 0.f);
-                const float s1 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.y, y0.y)), __fmul_rn(x1.y, y1.y)), 0.f);
-                const float s2 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.z, y0.z)), __fmul_rn(x1.z, y1.z)), 0.f);
-                const float s3 = __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.w, y0.w)), __fmul_rn(x1.w, y1.w)), 0.f);
-                r[c] = __fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3)));
-            }
-            m2t3[i] = make_float4(r[0], r[1], r[2], r[3]);
+            const float4 y0 = ct[0 * 64], y1 = ct[1 * 64], y2 = ct[2 * 64], y3 = ct[3 * 64];
+            const float4 y4 = ct[4 * 64], y5 = ct[5 * 64], y6 = ct[6 * 64], y7 = ct[7 * 64];
+            // fvec_inner_product, d = 8 (utils.cpp:509-533): s_l = ((0 + x_l y_l) + x_{l+4} y_{l+4}) + 0,
+            // result (s0+s1)+(s2+s3); .x/.y/.z/.w = centroids 4*lane+0..3
+#define VLQ_IP8(C)                                                                                        \
+    __fmul_rn(-2.f,                                                                                      \
+              __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.x, y0.C)), __fmul_rn(x1.x, y4.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.y, y1.C)), __fmul_rn(x1.y, y5.C)), 0.f)), \
+                        __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.z, y2.C)), __fmul_rn(x1.z, y6.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.w, y3.C)), __fmul_rn(x1.w, y7.C)), 0.f))))
+            m2t3[i] = make_float4(VLQ_IP8(x), VLQ_IP8(y), VLQ_IP8(z), VLQ_IP8(w));
+#undef VLQ_IP8
         }
     }
     __syncthreads();
