@@ -142,9 +142,180 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------
+// coarse distances, d <= 128 (the BASELINE shapes): query fragments in registers.
+// A workgroup owns 128 query rows (32 per wave) and walks `tiles_per_block` column
+// tiles of 64 centroids.  The wave's A operands for the WHOLE k range (<= 64 k-pairs)
+// are read once into 64 VGPRs, so LDS only holds the centroid tiles, double-buffered
+// (2 x 34 KB -> two workgroups per CU): tile j+1 is fetched into registers while tile
+// j is multiplied and written to the other buffer afterwards; one barrier per tile.
+// Same k order (0,1,2,...) and epilogue as coarse_dist_kernel -> identical bits.
+// ---------------------------------------------------------------------------
+template <int NU>   // k range padded to 8*NU
+__global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
+    const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
+    const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d,
+    int tiles_per_block) {
+    constexpr int KS = 4 * NU;        // k-pair steps
+    constexpr int S = KS + 4;         // padded row stride (floats) of a parity plane
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // 2 buffers x [2 parity][64][S]
+    constexpr int BUF = 2 * 64 * S;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * 128;
+    const int tile0 = blockIdx.y * tiles_per_block;
+    const int ntiles = (nlist + 63) / 64;
+    const bool vec_ok = (d % 4 == 0);
+
+    auto load4 = [&](const float* base, int64_t grow, int64_t lim, int kk) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow < lim && kk < d) {
+            const float* p = base + grow * d + kk;
+            if (vec_ok) x = *reinterpret_cast<const float4*>(p);
+            else {
+                x.x = p[0];
+                if (kk + 1 < d) x.y = p[1];
+                if (kk + 2 < d) x.z = p[2];
+                if (kk + 3 < d) x.w = p[3];
+            }
+        }
+        return x;
+    };
+
+    // ---- stage the 128-row query tile through LDS (uses both buffers), pull A fragments
+    for (int f = t; f < 128 * (2 * NU); f += 256) {
+        const int row = f / (2 * NU), v = f % (2 * NU);
+        const float4 x = load4(Q, i0 + row, nq, 4 * v);
+        // rows 0..63 -> buffer 0, rows 64..127 -> buffer 1
+        float* base = sm + (row >> 6) * BUF + (row & 63) * S + 2 * v;
+        *reinterpret_cast<float2*>(base) = make_float2(x.x, x.z);
+        *reinterpret_cast<float2*>(base + 64 * S) = make_float2(x.y, x.w);
+    }
+    __syncthreads();
+    float4 areg[NU];
+    {
+        const int row = wave * 32 + r;
+        const float* src = sm + (row >> 6) * BUF + h * 64 * S + (row & 63) * S;
+#pragma unroll
+        for (int u = 0; u < NU; u++) areg[u] = *reinterpret_cast<const float4*>(src + 4 * u);
+    }
+    float qnr[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        qnr[reg] = row < nq ? qn[row] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- centroid tiles
+    constexpr int NF = (64 * 2 * NU) / 256;     // float4 per thread per tile (= NU / 2)
+    float4 pre[NF];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const int f = t + 256 * i;
+            const int row = f / (2 * NU), v = f % (2 * NU);
+            pre[i] = load4(Cn, (int64_t)tile * 64 + row, nlist, 4 * v);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const int f = t + 256 * i;
+            const int row = f / (2 * NU), v = f % (2 * NU);
+            float* base = sm + buf * BUF + row * S + 2 * v;
+            *reinterpret_cast<float2*>(base) = make_float2(pre[i].x, pre[i].z);
+            *reinterpret_cast<float2*>(base + 64 * S) = make_float2(pre[i].y, pre[i].w);
+        }
+    };
+    const int tend = min(ntiles, tile0 + tiles_per_block);
+    if (tile0 >= tend) return;
+    fetch(tile0);
+    stash(0);
+    if (tile0 + 1 < tend) fetch(tile0 + 1);
+    __syncthreads();
+    for (int tile = tile0; tile < tend; tile++) {
+        const int buf = (tile - tile0) & 1;
+        f32x16 acc[2];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[tj][reg] = 0.f;
+        const float* bsrc = sm + buf * BUF + h * 64 * S + r * S;
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc + 4 * u);
+            const float4 b1 = *reinterpret_cast<const float4*>(bsrc + 32 * S + 4 * u);
+            const float4 av = areg[u];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1], 0, 0, 0);
+        }
+        // next tile: registers -> the other buffer (free since the barrier of the previous
+        // iteration), then request the tile after it
+        if (tile + 1 < tend) {
+            stash(buf ^ 1);
+            if (tile + 2 < tend) fetch(tile + 2);
+        }
+        // epilogue of this tile
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const int col = tile * 64 + tj * 32 + r;
+            const float cnv = col < nlist ? cn[col] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (row < nq && col < nlist)
+                    out[row * nlist + col] =
+                        __fsub_rn(__fadd_rn(qnr[reg], cnv), __fmul_rn(2.f, acc[tj][reg]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NU>
+static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
+                               float* out, int64_t nq, int nlist, int d, hipStream_t s) {
+    constexpr int S = 4 * NU + 4;
+    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const int64_t rb = (nq + 127) / 128;
+    const int ntiles = (nlist + 63) / 64;
+    // tiles per workgroup: fill whole rounds of 2 workgroups x 256 CUs with the least idle tail
+    int best_t = 1;
+    double best_cost = 1e30;
+    for (int tpb = 1; tpb <= 16; tpb++) {
+        const int64_t blocks = rb * ((ntiles + tpb - 1) / tpb);
+        const int64_t rounds = (blocks + 511) / 512;
+        const double cost = (double)rounds * (tpb + 0.6);   // 0.6 tile-times ~ per-workgroup prologue
+        if (cost < best_cost) { best_cost = cost; best_t = tpb; }
+    }
+    dim3 grid((unsigned)rb, (unsigned)((ntiles + best_t - 1) / best_t));
+    hipLaunchKernelGGL(coarse_dist_areg_kernel<NU>, grid, dim3(256), smem, s, q, c, qn, cn, out, nq,
+                       nlist, d, best_t);
+}
+
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
                              float* out, int64_t nq, int nlist, int d, hipStream_t s) {
     if (nq <= 0 || nlist <= 0) return;
+    if (d <= 128) {
+        if (d <= 32) launch_coarse_areg<4>(q, c, qn, cn, out, nq, nlist, d, s);
+        else if (d <= 64) launch_coarse_areg<8>(q, c, qn, cn, out, nq, nlist, d, s);
+        else if (d <= 96) launch_coarse_areg<12>(q, c, qn, cn, out, nq, nlist, d, s);
+        else launch_coarse_areg<16>(q, c, qn, cn, out, nq, nlist, d, s);
+        return;
+    }
     constexpr int KC = 64;
     const size_t smem = 2 * 2 * 128 * (KC / 2 + 4) * sizeof(float);
     static bool attr_set = false;
