@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(
 // j is multiplied and written to the other buffer afterwards; one barrier per tile.
 // Same k order (0,1,2,...) and epilogue as coarse_dist_kernel -> identical bits.
 // ---------------------------------------------------------------------------
-template <int NU>   // k range padded to 8*NU
+template <int NU, bool VEC>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
 __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
     const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d,
@@ -165,19 +165,29 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     const int64_t i0 = (int64_t)blockIdx.x * 128;
     const int tile0 = blockIdx.y * tiles_per_block;
     const int ntiles = (nlist + 63) / 64;
-    const bool vec_ok = (d % 4 == 0);
 
+    // Branch-free loads: a conditional around a load makes hipcc wait for every element
+    // separately (serialised L2 round trips).  Rows past the end are clamped -- their
+    // products land in outputs that are never stored -- and the k padding is zeroed by a
+    // select after the load.
     auto load4 = [&](const float* base, int64_t grow, int64_t lim, int kk) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow < lim && kk < d) {
-            const float* p = base + grow * d + kk;
-            if (vec_ok) x = *reinterpret_cast<const float4*>(p);
-            else {
-                x.x = p[0];
-                if (kk + 1 < d) x.y = p[1];
-                if (kk + 2 < d) x.z = p[2];
-                if (kk + 3 < d) x.w = p[3];
-            }
+        const int64_t rowc = grow < lim ? grow : lim - 1;
+        float4 x;
+        if (VEC) {
+            const int kc = kk < d ? kk : d - 4;
+            x = *reinterpret_cast<const float4*>(base + rowc * d + kc);
+            if (kk >= d) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float* p = base + rowc * d;
+            const int dm = d - 1;
+            x.x = p[min(kk + 0, dm)];
+            x.y = p[min(kk + 1, dm)];
+            x.z = p[min(kk + 2, dm)];
+            x.w = p[min(kk + 3, dm)];
+            if (kk + 0 >= d) x.x = 0.f;
+            if (kk + 1 >= d) x.y = 0.f;
+            if (kk + 2 >= d) x.z = 0.f;
+            if (kk + 3 >= d) x.w = 0.f;
         }
         return x;
     };
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
         const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        qnr[reg] = row < nq ? qn[row] : 0.f;
+        qnr[reg] = qn[row < nq ? row : nq - 1];
     }
     __syncthreads();
 
@@ -279,31 +289,39 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     }
 }
 
-template <int NU>
-static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
+template <int NU, bool VEC>
+static void launch_coarse_areg_t(const float* q, const float* c, const float* qn, const float* cn,
                                float* out, int64_t nq, int nlist, int d, hipStream_t s) {
     constexpr int S = 4 * NU + 4;
     const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
-    // tiles per workgroup: fill whole rounds of 2 workgroups x 256 CUs with the least idle tail
+    // tiles per workgroup: the MFMA pipe of a CU is shared by its (up to 2) resident
+    // workgroups, so the time is ~ (tiles + prologue) of the busiest CU over all rounds
     int best_t = 1;
     double best_cost = 1e30;
-    for (int tpb = 1; tpb <= 16; tpb++) {
+    for (int tpb = 1; tpb <= 32; tpb++) {
         const int64_t blocks = rb * ((ntiles + tpb - 1) / tpb);
-        const int64_t rounds = (blocks + 511) / 512;
-        const double cost = (double)rounds * (tpb + 0.6);   // 0.6 tile-times ~ per-workgroup prologue
+        const int64_t per_cu = (blocks + 255) / 256;            // workgroups the busiest CU runs
+        const double cost = (double)per_cu * (tpb + 0.5);
         if (cost < best_cost) { best_cost = cost; best_t = tpb; }
     }
     dim3 grid((unsigned)rb, (unsigned)((ntiles + best_t - 1) / best_t));
-    hipLaunchKernelGGL(coarse_dist_areg_kernel<NU>, grid, dim3(256), smem, s, q, c, qn, cn, out, nq,
-                       nlist, d, best_t);
+    hipLaunchKernelGGL((coarse_dist_areg_kernel<NU, VEC>), grid, dim3(256), smem, s, q, c, qn, cn, out,
+                       nq, nlist, d, best_t);
+}
+
+template <int NU>
+static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
+                               float* out, int64_t nq, int nlist, int d, hipStream_t s) {
+    if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true>(q, c, qn, cn, out, nq, nlist, d, s);
+    else launch_coarse_areg_t<NU, false>(q, c, qn, cn, out, nq, nlist, d, s);
 }
 
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
