@@ -7,7 +7,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libvlq_ivfpq.so")
+_SO = os.environ.get("VLQ_LIB_PATH") or os.path.join(_CSRC, "libvlq_ivfpq.so")   # override: kernel experiments
 
 # every symbol include/vlq_ivfpq.h declares
 SYMBOLS = [

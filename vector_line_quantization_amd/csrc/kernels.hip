@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+#ifdef VLQ_EXP_NOSTORE
+                if (row < nq && col < nlist && acc[tj][reg] == 12345.678f)
+#else
                 if (row < nq && col < nlist)
+#endif
                     out[row * nlist + col] =
                         __fsub_rn(__fadd_rn(qnr[reg], cnv), __fmul_rn(2.f, acc[tj][reg]));
             }
