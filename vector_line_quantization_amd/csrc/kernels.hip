@@ -272,21 +272,51 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
             stash(buf ^ 1);
             if (tile + 2 < tend) fetch(tile + 2);
         }
-        // epilogue of this tile
+        // epilogue of this tile.  A lane holds one column and, per group of 4 registers,
+        // 4 consecutive rows; a 4x4 transpose inside each lane quad (two DPP exchange
+        // steps) turns that into one row x 4 consecutive columns, so the tile leaves as
+        // 16-byte stores that cover whole 128-byte lines (8 rows per instruction) --
+        // 4x fewer store instructions than dword stores, which were issue-bound.
+        const bool full = (tile * 64 + 64 <= nlist) && ((nlist & 3) == 0);
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
             const int col = tile * 64 + tj * 32 + r;
-            const float cnv = col < nlist ? cn[col] : 0.f;
+            const float cnv = cn[col < nlist ? col : nlist - 1];
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-#ifdef VLQ_EXP_NOSTORE
-                if (row < nq && col < nlist && acc[tj][reg] == 12345.678f)
-#else
-                if (row < nq && col < nlist)
-#endif
-                    out[row * nlist + col] =
-                        __fsub_rn(__fadd_rn(qnr[reg], cnv), __fmul_rn(2.f, acc[tj][reg]));
+            for (int g = 0; g < 4; g++) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)   // (x_norm + y_norm) - 2*ip, utils.cpp:884
+                    v[i] = __fsub_rn(__fadd_rn(qnr[4 * g + i], cnv), __fmul_rn(2.f, acc[tj][4 * g + i]));
+                if (full) {
+                    // step 1: lanes l, l^1 exchange across register pairs (0,1) (2,3)
+                    {
+                        const bool odd = lane & 1;
+                        float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+                        s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
+                        s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, false));
+                        if (odd) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+                    }
+                    // step 2: lanes l, l^2 exchange across register pairs (0,2) (1,3)
+                    {
+                        const bool up = lane & 2;
+                        float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3];
+                        s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x4E, 0xf, 0xf, false));
+                        s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xf, 0xf, false));
+                        if (up) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
+                    }
+                    // lane (r = 4q + i, h): row 8g + 4h + i, columns 4q .. 4q+3
+                    const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + (r & 3);
+                    if (row < nq)
+                        *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + i;
+                        if (row < nq && col < nlist) out[row * nlist + col] = v[i];
+                    }
+                }
             }
         }
         __syncthreads();
