@@ -26,3 +26,21 @@ for _ in range(reps):
 torch.cuda.synchronize()
 p = g.profile_read()
 print("lib=%s coarse_ms=%.4f" % (os.environ.get("VLQ_LIB_PATH", "default"), p["coarse_ms"] / reps))
+
+# scan stage on a synthetic index with SIFT1M-like list sizes
+nb = 1000000
+lens = rng.multinomial(nb, rng.dirichlet(np.full(nlist, 1.2)))
+off = np.zeros(nlist + 1, np.int64); np.cumsum(lens, out=off[1:])
+g.set_lists(rng.integers(0, 256, (nb, M), dtype=np.uint8), np.arange(nb, dtype=np.int64), off)
+D = torch.empty((nq, 10), dtype=torch.float32, device="cuda")
+I = torch.empty((nq, 10), dtype=torch.int64, device="cuda")
+for _ in range(2):
+    g.search_preassigned(x, keys, cd, 10, D=D, I=I)
+torch.cuda.synchronize()
+g.stats(reset=True); g.profile_read(reset=True)
+for _ in range(reps):
+    g.search_preassigned(x, keys, cd, 10, D=D, I=I)
+torch.cuda.synchronize()
+p = g.profile_read()
+_, ncode = g.stats()
+print("scan_ms=%.4f ncode/query=%.0f -> %.0f GB/s algorithmic" % (p["scan_ms"] / reps, ncode / reps / nq, ncode / reps * 16 / (p["scan_ms"] / reps * 1e-3) / 1e9))

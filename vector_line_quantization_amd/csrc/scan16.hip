@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
             dis = __fadd_rn(dis, L[13 * 256 + ((cc.w >> 8) & 255u)]);
             dis = __fadd_rn(dis, L[14 * 256 + ((cc.w >> 16) & 255u)]);
             dis = __fadd_rn(dis, L[15 * 256 + (cc.w >> 24)]);
+#ifdef VLQ_EXP_NOSELECT
+            sel.offer(dis, pos0 + j, valid && dis < -1e30f);
+#else
             sel.offer(dis, pos0 + j, valid);
+#endif
             cc = cn;
         }
         nscan += len;
