@@ -141,32 +141,25 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
     WaveSelect<KPL> sel;
     sel.init(a.k, queue + wave * 64, lane);
 
-    // ---- probe loop, software-pipelined TWO live probes ahead -----------------------
-    // A random 16 KB term2 row comes from the Infinity Cache / HBM with 1-2 us of
-    // latency under load while one probe of ~250 codes is ~1 us of work, so one probe of
-    // lookahead leaves the row fetch exposed; two rows (32 VGPRs) in flight per
-    // workgroup cover it.
-    struct Pre { float4 t2[4]; uint4 c0; int idx; };
-    auto fetch = [&](int p) {
-        Pre f;
-        f.c0 = make_uint4(0, 0, 0, 0);
-        while (p < np_eff && pkey[p] < 0) p++;         // first live probe at or after p
-        f.idx = p;
+    // ---- probe loop, software-pipelined one live probe ahead ----------------------
+    float4 t2r[4];
+    uint4 c0 = make_uint4(0, 0, 0, 0);
+    auto prefetch = [&](int p) {
+        // first live probe at or after p; returns its index (or np_eff)
+        while (p < np_eff && pkey[p] < 0) p++;
         if (p < np_eff) {
             const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)pkey[p] * E);
 #pragma unroll
-            for (int i = 0; i < 4; i++) f.t2[i] = src[i * 256 + t];
+            for (int i = 0; i < 4; i++) t2r[i] = src[i * 256 + t];
             if ((uint32_t)t < plen[p])
-                f.c0 = reinterpret_cast<const uint4*>(a.codes)[poff[p] + t];
+                c0 = reinterpret_cast<const uint4*>(a.codes)[poff[p] + t];
         }
-        return f;
+        return p;
     };
-    Pre A = fetch(0);
-    Pre B = fetch(A.idx + 1);
+    int ik = prefetch(0);
     int buf = 0;
     uint64_t nscan = 0;
-    while (A.idx < np_eff) {
-        const int ik = A.idx;
+    while (ik < np_eff) {
         const uint32_t len = plen[ik];
         const float dis0 = pd0[ik];
         const uint32_t pos0 = cum[ik];
@@ -176,15 +169,14 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float4 s;
-            s.x = __fadd_rn(A.t2[i].x, m2t3[i].x);
-            s.y = __fadd_rn(A.t2[i].y, m2t3[i].y);
-            s.z = __fadd_rn(A.t2[i].z, m2t3[i].z);
-            s.w = __fadd_rn(A.t2[i].w, m2t3[i].w);
+            s.x = __fadd_rn(t2r[i].x, m2t3[i].x);
+            s.y = __fadd_rn(t2r[i].y, m2t3[i].y);
+            s.z = __fadd_rn(t2r[i].z, m2t3[i].z);
+            s.w = __fadd_rn(t2r[i].w, m2t3[i].w);
             reinterpret_cast<float4*>(L)[i * 256 + t] = s;
         }
-        uint4 cc = A.c0;
-        A = B;
-        B = fetch(A.idx + 1);
+        uint4 cc = c0;
+        const int nxt = prefetch(ik + 1);
         __syncthreads();
         for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += 256) {
             const uint32_t j = j0 + lane;
@@ -219,6 +211,7 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
         }
         nscan += len;
         buf ^= 1;
+        ik = nxt;
     }
 
     merge_and_emit<KPL>(sel, smraw, cum, a, q, wave, lane,
