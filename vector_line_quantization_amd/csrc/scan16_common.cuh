@@ -1,0 +1,163 @@
+// Pieces shared by the 16-byte-code scan kernels (scan16.hip, scan16x2.hip): identical
+// arithmetic in both, so results cannot depend on which kernel served a query.
+#pragma once
+#include "kernels.h"
+#include "wave_topk.cuh"
+
+namespace vlq {
+
+// -2 * sim_table_2 of query q (ProductQuantizer::compute_inner_prod_table,
+// ProductQuantizer.cpp:424-436), 16 entries per thread.  Entry e = 4*(i*256+t)+c ->
+// sub-quantizer m = 4i + wave (wave-uniform), centroid j = 4*lane + c.
+__device__ __forceinline__ void load_query_table16(const ScanArgs& a, int64_t q, int t, int lane,
+                                                   int wave, float4 (&m2t3)[4]) {
+    constexpr int E = 4096;
+    if (a.qtab) {
+        const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 v = qt[i * 256 + t];
+            m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
+                                  __fmul_rn(-2.f, v.w));
+        }
+    } else {
+        // codebook read from its transposed copy pq_cent_t[m][component][j]: the four
+        // centroids j = 4*lane..4*lane+3 of one component are one 16-byte load, a wave
+        // reads 1 KiB contiguous per instruction
+        const float* qv = a.queries + q * 128;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = 4 * i + wave;
+            const float4* ct = reinterpret_cast<const float4*>(a.pq_cent_t + (size_t)m * 8 * 256) + lane;
+            const float4 x0 = *reinterpret_cast<const float4*>(qv + m * 8);
+            const float4 x1 = *reinterpret_cast<const float4*>(qv + m * 8 + 4);
+            const float4 y0 = ct[0 * 64], y1 = ct[1 * 64], y2 = ct[2 * 64], y3 = ct[3 * 64];
+            const float4 y4 = ct[4 * 64], y5 = ct[5 * 64], y6 = ct[6 * 64], y7 = ct[7 * 64];
+            // fvec_inner_product, d = 8 (utils.cpp:509-533): s_l = ((0 + x_l y_l) + x_{l+4} y_{l+4}) + 0,
+            // result (s0+s1)+(s2+s3); .x/.y/.z/.w = centroids 4*lane+0..3
+#define VLQ_IP8(C)                                                                                        \
+    __fmul_rn(-2.f,                                                                                      \
+              __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.x, y0.C)), __fmul_rn(x1.x, y4.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.y, y1.C)), __fmul_rn(x1.y, y5.C)), 0.f)), \
+                        __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.z, y2.C)), __fmul_rn(x1.z, y6.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.w, y3.C)), __fmul_rn(x1.w, y7.C)), 0.f))))
+            m2t3[i] = make_float4(VLQ_IP8(x), VLQ_IP8(y), VLQ_IP8(z), VLQ_IP8(w));
+#undef VLQ_IP8
+        }
+    }
+}
+
+// dis = dis0 + tab[0][c0] + ... + tab[15][c15], strictly left to right
+// (IndexIVFPQ.cpp:788-794); L = LUT [16][256] in LDS, cc = one 16-byte code
+__device__ __forceinline__ float adc16(const float* L, const uint4 cc, float dis) {
+    dis = __fadd_rn(dis, L[0 * 256 + (cc.x & 255u)]);
+    dis = __fadd_rn(dis, L[1 * 256 + ((cc.x >> 8) & 255u)]);
+    dis = __fadd_rn(dis, L[2 * 256 + ((cc.x >> 16) & 255u)]);
+    dis = __fadd_rn(dis, L[3 * 256 + (cc.x >> 24)]);
+    dis = __fadd_rn(dis, L[4 * 256 + (cc.y & 255u)]);
+    dis = __fadd_rn(dis, L[5 * 256 + ((cc.y >> 8) & 255u)]);
+    dis = __fadd_rn(dis, L[6 * 256 + ((cc.y >> 16) & 255u)]);
+    dis = __fadd_rn(dis, L[7 * 256 + (cc.y >> 24)]);
+    dis = __fadd_rn(dis, L[8 * 256 + (cc.z & 255u)]);
+    dis = __fadd_rn(dis, L[9 * 256 + ((cc.z >> 8) & 255u)]);
+    dis = __fadd_rn(dis, L[10 * 256 + ((cc.z >> 16) & 255u)]);
+    dis = __fadd_rn(dis, L[11 * 256 + (cc.z >> 24)]);
+    dis = __fadd_rn(dis, L[12 * 256 + (cc.w & 255u)]);
+    dis = __fadd_rn(dis, L[13 * 256 + ((cc.w >> 8) & 255u)]);
+    dis = __fadd_rn(dis, L[14 * 256 + ((cc.w >> 16) & 255u)]);
+    dis = __fadd_rn(dis, L[15 * 256 + (cc.w >> 24)]);
+    return dis;
+}
+
+// sim_table = term2[key] + (-2) * sim_table_2  (fvec_madd, IndexIVFPQ.cpp:641-644):
+// 16 entries per thread, four 16-byte LDS stores
+__device__ __forceinline__ void build_lut16(float* L, int t, const float4 (&t2)[4],
+                                            const float4 (&m2t3)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float4 s;
+        s.x = __fadd_rn(t2[i].x, m2t3[i].x);
+        s.y = __fadd_rn(t2[i].y, m2t3[i].y);
+        s.z = __fadd_rn(t2[i].z, m2t3[i].z);
+        s.w = __fadd_rn(t2[i].w, m2t3[i].w);
+        reinterpret_cast<float4*>(L)[i * 256 + t] = s;
+    }
+}
+
+// Per-query probe metadata in LDS.
+struct ProbeMeta {
+    int64_t* poff;    // [nprobe] list start (codes/ids row)
+    uint32_t* cum;    // [nprobe+1] scan position of the probe's first code
+    uint32_t* plen;   // [nprobe]
+    int32_t* pkey;    // [nprobe] list id, -1 = not visited (invalid key, empty list, behind max_codes)
+    float* pd0;       // [nprobe] coarse distance
+    __device__ __forceinline__ static size_t bytes(int nprobe) { return (size_t)nprobe * 24 + 8; }
+    __device__ __forceinline__ void carve(unsigned char* base, int nprobe) {
+        poff = reinterpret_cast<int64_t*>(base);
+        cum = reinterpret_cast<uint32_t*>(poff + nprobe);
+        plen = cum + nprobe + 1;
+        pkey = reinterpret_cast<int32_t*>(plen + nprobe);
+        pd0 = reinterpret_cast<float*>(pkey + nprobe);
+    }
+};
+
+// step 1 (all threads, stride nthr starting at t0): gather keys / offsets / lengths
+__device__ __forceinline__ bool probe_meta_fill(const ScanArgs& a, int64_t q, ProbeMeta& pm, int t0,
+                                                int nthr) {
+    const int64_t* kq = a.keys + q * a.nprobe;
+    const float* cq = a.coarse_dis + q * a.nprobe;
+    bool badkey = false;
+    for (int p = t0; p < a.nprobe; p += nthr) {
+        const int64_t key = kq[p];
+        if (key >= a.nlist) badkey = true;                 // IndexIVFPQ.cpp:1008-1011
+        const bool live = key >= 0 && key < a.nlist;
+        int64_t off = 0, len = 0;
+        if (live) { off = a.list_off[key]; len = a.list_off[key + 1] - off; }
+        pm.poff[p] = off;
+        pm.plen[p] = (uint32_t)len;
+        pm.pkey[p] = (live && len > 0) ? (int32_t)key : -1;   // empty lists are skipped (:1016)
+        pm.pd0[p] = cq[p];
+    }
+    return badkey;
+}
+
+// step 2 (ONE wave, after a barrier): exclusive prefix sum of the list lengths and the
+// max_codes cut (IndexIVFPQ.cpp:1033: stop after the probe that reaches it); probes behind
+// the cut are marked not visited.  Returns the number of probes visited.
+__device__ __forceinline__ int probe_meta_scan(const ScanArgs& a, ProbeMeta& pm, int lane) {
+    const int per = (a.nprobe + 63) >> 6;
+    const int p0 = lane * per;
+    uint64_t local = 0;
+    for (int i = 0; i < per; i++) { const int p = p0 + i; if (p < a.nprobe) local += pm.plen[p]; }
+    uint64_t incl = local;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)incl, sft, 64);
+        const uint32_t hi = __shfl_up((uint32_t)(incl >> 32), sft, 64);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        if (lane >= sft) incl += o;
+    }
+    uint64_t run = incl - local;
+    int cut = a.nprobe;                                  // first probe index AFTER the cut
+    for (int i = 0; i < per; i++) {
+        const int p = p0 + i;
+        if (p < a.nprobe) {
+            pm.cum[p] = (uint32_t)run;
+            run += pm.plen[p];
+            if (a.max_codes && run >= (uint64_t)a.max_codes && cut == a.nprobe) cut = p + 1;
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) cut = min(cut, __shfl_xor(cut, sft, 64));
+    if (lane == 63) pm.cum[a.nprobe] = (uint32_t)incl;
+    __builtin_amdgcn_wave_barrier();
+    if (cut < a.nprobe) {
+        const uint32_t endpos = pm.cum[cut];
+        __builtin_amdgcn_wave_barrier();
+        for (int p = cut + lane; p <= a.nprobe; p += 64) pm.cum[p] = endpos;
+        for (int p = cut + lane; p < a.nprobe; p += 64) pm.pkey[p] = -1;
+    }
+    return cut;
+}
+
+}  // namespace vlq
