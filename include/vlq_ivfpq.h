@@ -56,7 +56,8 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
 void vlq_ivfpq_destroy(vlq_ivfpq_t h);
 
 /* GpuResources::getDefaultStream (gpu/GpuResources.h:36): run on the caller's
- * hipStream_t (NULL = the index's own stream). */
+ * hipStream_t.  Until this is called the index uses a private non-blocking stream;
+ * NULL selects the HIP null (legacy default) stream, e.g. torch's default stream. */
 int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream);
 
 /* GpuIndexIVF::copyFrom: coarse centroids = IndexFlatL2::xb of the quantizer

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""How many probe lists do queries adjacent in nearest-centroid order share? (bench data)"""
+import os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+args = types.SimpleNamespace(d=128, nlist=4096, M=16, nt=100000, nb=1000000, sigma=0.03, gmm_centres=2000)
+dev = torch.device("cuda", 0)
+g, centres, coarse, pq, xb = bench.build_index(args, dev)
+gen = torch.Generator(device=dev); gen.manual_seed(33)
+xq = bench.gmm(torch, gen, centres, 10000, args.sigma, dev)
+cd, keys = g.coarse_search(xq, 32)
+keys = keys.cpu().numpy()
+order = np.argsort(keys[:, 0], kind="stable")
+ks = keys[order]
+for name, kk in (("sorted by top-1", ks), ("unsorted", keys)):
+    shared = [len(set(kk[i]) & set(kk[i + 1])) for i in range(0, len(kk) - 1, 2)]
+    print(name, "mean shared probes per pair: %.2f of 32; pairs with same top-1: %.3f" % (np.mean(shared), np.mean(kk[0:-1:2, 0] == kk[1::2, 0])))
+# lexicographic on (top1, top2)
+order2 = np.lexsort((keys[:, 1], keys[:, 0])); k2 = keys[order2]
+shared = [len(set(k2[i]) & set(k2[i + 1])) for i in range(0, len(k2) - 1, 2)]
+print("sorted by (top1,top2): %.2f" % np.mean(shared))
+u, c = np.unique(keys[:, 0], return_counts=True)
+print("distinct top-1 cells:", len(u), "queries in cells with >=2 queries: %.3f" % (c[c >= 2].sum() / len(keys)))

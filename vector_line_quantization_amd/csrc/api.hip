@@ -379,7 +379,7 @@ int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     TRY(set_dev(h));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = the HIP null stream
     return VLQ_OK;
 }
 
