@@ -17,7 +17,7 @@
 namespace vlq {
 
 template <int KPL>
-__global__ __launch_bounds__(256, 4) void scan16x2_kernel(ScanArgs a, int lut_region) {
+__global__ __launch_bounds__(256, (KPL <= 4 ? 4 : 2)) void scan16x2_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [2][E]
