@@ -276,8 +276,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                                         h->ws_qorder.as<int>(), h->stream);
                 a.qorder = h->ws_qorder.as<int>();
             }
-            if (a.qorder && nprobe <= 128) vlq::launch_scan16x2(a, h->stream);
-            else vlq::launch_scan16(a, h->stream);
+            vlq::launch_scan16(a, h->stream);
         } else {
             vlq::launch_scan(a, h->stream);
         }

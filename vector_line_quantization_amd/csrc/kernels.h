@@ -56,8 +56,6 @@ struct ScanArgs {
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
-// same, two queries (adjacent in qorder) per workgroup sharing their term2 rows (scan16x2.hip)
-void launch_scan16x2(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s);

@@ -18,15 +18,17 @@
 
 namespace vlq {
 
-template <int KPL>
-__global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region) {
+template <int KPL, int NW>
+__global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
+    constexpr int NT = 64 * NW;       // threads per workgroup
+    constexpr int NI = 16 / NW;       // float4 of the LUT per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [2][E]
-    u64* queue = reinterpret_cast<u64*>(smraw + lut_region);              // [4][64]
+    u64* queue = reinterpret_cast<u64*>(smraw + lut_region);              // [NW][64]
     ProbeMeta pm;
-    pm.carve(reinterpret_cast<unsigned char*>(queue + 4 * 64), a.nprobe);
-    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + 4 * 64) +
+    pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64), a.nprobe);
+    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) +
                                                ProbeMeta::bytes(a.nprobe));
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -42,9 +44,9 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
     const int64_t* kq = a.keys + q * a.nprobe;
 
     // ---- per-query set-up -------------------------------------------------------
-    const bool badkey = probe_meta_fill(a, q, pm, t, 256);
-    float4 m2t3[4];
-    load_query_table16(a, q, t, lane, wave, m2t3);
+    const bool badkey = probe_meta_fill(a, q, pm, t, NT);
+    float4 m2t3[NI];
+    load_query_table16<NI>(a, q, t, lane, wave, m2t3);
     __syncthreads();
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
     sel.init(a.k, queue + wave * 64, lane);
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
-    float4 t2r[4];
+    float4 t2r[NI];
     uint4 c0 = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](int p) {
         // first live probe at or after p; returns its index (or np_eff)
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
         if (p < np_eff) {
             const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)pm.pkey[p] * E);
 #pragma unroll
-            for (int i = 0; i < 4; i++) t2r[i] = src[i * 256 + t];
+            for (int i = 0; i < NI; i++) t2r[i] = src[i * NT + t];
             if ((uint32_t)t < pm.plen[p])
                 c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
         }
@@ -80,13 +82,13 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
         const uint32_t pos0 = pm.cum[ik];
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + pm.poff[ik];
         float* L = lut + buf * E;
-        build_lut16(L, t, t2r, m2t3);
+        build_lut16<NI>(L, t, t2r, m2t3);
         uint4 cc = c0;
         const int nxt = prefetch(ik + 1);
         __syncthreads();
-        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += 256) {
+        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
             const uint32_t j = j0 + lane;
-            const uint32_t jn = j + 256;
+            const uint32_t jn = j + NT;
             uint4 cn = make_uint4(0, 0, 0, 0);
             if (jn < len) cn = cp[jn];
             const bool valid = j < len;
@@ -99,36 +101,39 @@ __global__ __launch_bounds__(256) void scan16_kernel(ScanArgs a, int lut_region)
         ik = nxt;
     }
 
-    merge_and_emit<KPL>(sel, smraw, pm.cum, a, q, wave, lane,
+    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, q, wave, lane,
                         [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
     if (badkey) *a.bad_key = 1;
 }
 
-template <int KPL>
+template <int KPL, int NW>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_kernel<KPL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_kernel<KPL, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_smem = smem;
     }
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
-    hipLaunchKernelGGL((scan16_kernel<KPL>), dim3(grid), dim3(256), smem, s, a, lut_region);
+    hipLaunchKernelGGL((scan16_kernel<KPL, NW>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
 
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     if (a_in.nq <= 0) return;
     ScanArgs a = a_in;
     a.xcd_chunk = (int)((a.nq + 7) / 8);
+    // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
+    // larger k keeps more selection state per wave, so stay at 4 waves
+    const int nw = a.k <= 64 ? 8 : 4;
     size_t lutb = (size_t)2 * 4096 * 4;
-    const size_t merge = (size_t)4 * a.k * 8;
+    const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = 4 * 64 * 8 + (size_t)a.nprobe * (8 + 4 + 4 + 4 + 4) + 4 + 64;
+    const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 4 + 64;
     const size_t smem = lutb + tail;
-    if (a.k <= 64) launch_scan16_t<1>(a, (int)lutb, smem, s);
-    else if (a.k <= 256) launch_scan16_t<4>(a, (int)lutb, smem, s);
-    else launch_scan16_t<16>(a, (int)lutb, smem, s);
+    if (a.k <= 64) launch_scan16_t<1, 8>(a, (int)lutb, smem, s);
+    else if (a.k <= 256) launch_scan16_t<4, 4>(a, (int)lutb, smem, s);
+    else launch_scan16_t<16, 4>(a, (int)lutb, smem, s);
 }
 
 // ---------------------------------------------------------------------------

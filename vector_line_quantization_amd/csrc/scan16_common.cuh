@@ -8,15 +8,18 @@ namespace vlq {
 
 // -2 * sim_table_2 of query q (ProductQuantizer::compute_inner_prod_table,
 // ProductQuantizer.cpp:424-436), 16 entries per thread.  Entry e = 4*(i*256+t)+c ->
-// sub-quantizer m = 4i + wave (wave-uniform), centroid j = 4*lane + c.
+// sub-quantizer m = NWV*i + wave (wave-uniform), centroid j = 4*lane + c.
+template <int NI>   // NI float4 per thread: 4 with 256 threads, 2 with 512
 __device__ __forceinline__ void load_query_table16(const ScanArgs& a, int64_t q, int t, int lane,
-                                                   int wave, float4 (&m2t3)[4]) {
+                                                   int wave, float4 (&m2t3)[NI]) {
     constexpr int E = 4096;
+    constexpr int NT = 1024 / NI;     // threads per workgroup
+    constexpr int NWV = NT / 64;      // waves per workgroup
     if (a.qtab) {
         const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 v = qt[i * 256 + t];
+        for (int i = 0; i < NI; i++) {
+            const float4 v = qt[i * NT + t];
             m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
                                   __fmul_rn(-2.f, v.w));
         }
@@ -26,8 +29,8 @@ __device__ __forceinline__ void load_query_table16(const ScanArgs& a, int64_t q,
         // reads 1 KiB contiguous per instruction
         const float* qv = a.queries + q * 128;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int m = 4 * i + wave;
+        for (int i = 0; i < NI; i++) {
+            const int m = NWV * i + wave;
             const float4* ct = reinterpret_cast<const float4*>(a.pq_cent_t + (size_t)m * 8 * 256) + lane;
             const float4 x0 = *reinterpret_cast<const float4*>(qv + m * 8);
             const float4 x1 = *reinterpret_cast<const float4*>(qv + m * 8 + 4);
@@ -70,17 +73,19 @@ __device__ __forceinline__ float adc16(const float* L, const uint4 cc, float dis
 }
 
 // sim_table = term2[key] + (-2) * sim_table_2  (fvec_madd, IndexIVFPQ.cpp:641-644):
-// 16 entries per thread, four 16-byte LDS stores
-__device__ __forceinline__ void build_lut16(float* L, int t, const float4 (&t2)[4],
-                                            const float4 (&m2t3)[4]) {
+// 4*NI entries per thread, NI 16-byte LDS stores
+template <int NI>
+__device__ __forceinline__ void build_lut16(float* L, int t, const float4 (&t2)[NI],
+                                            const float4 (&m2t3)[NI]) {
+    constexpr int NT = 1024 / NI;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NI; i++) {
         float4 s;
         s.x = __fadd_rn(t2[i].x, m2t3[i].x);
         s.y = __fadd_rn(t2[i].y, m2t3[i].y);
         s.z = __fadd_rn(t2[i].z, m2t3[i].z);
         s.w = __fadd_rn(t2[i].w, m2t3[i].w);
-        reinterpret_cast<float4*>(L)[i * 256 + t] = s;
+        reinterpret_cast<float4*>(L)[i * NT + t] = s;
     }
 }
 

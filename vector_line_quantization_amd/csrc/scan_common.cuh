@@ -1,4 +1,4 @@
-// Shared tail of the scan kernels: merge the four waves' running selections and
+// Shared tail of the scan kernels: merge the NW waves' running selections and
 // emit (distance, label) rows.  Scan positions are translated back to
 // (probe, offset) with the per-query prefix sums `cum` kept in LDS, then to the
 // stored id -- the only place the id array is touched.
@@ -9,13 +9,13 @@
 namespace vlq {
 
 // resolve(p, lkey, loff): list id and list start offset of probe p
-template <int KPL, typename Resolve>
+template <int KPL, int NW = 4, typename Resolve>
 __device__ __forceinline__ void merge_and_emit(WaveSelect<KPL>& sel, unsigned char* smraw,
                                                const uint32_t* cum, const ScanArgs& a, int64_t q,
                                                int wave, int lane, Resolve resolve) {
     sel.flush();
     __syncthreads();                           // LUT buffers are free from here on
-    u64* mb = reinterpret_cast<u64*>(smraw);   // [4][k], aliases the LUT
+    u64* mb = reinterpret_cast<u64*>(smraw);   // [NW][k], aliases the LUT
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const int e = r * 64 + lane;
@@ -23,7 +23,7 @@ __device__ __forceinline__ void merge_and_emit(WaveSelect<KPL>& sel, unsigned ch
     }
     __syncthreads();
     if (wave != 0) return;
-    for (int w = 1; w < 4; w++)
+    for (int w = 1; w < NW; w++)
         for (int e0 = 0; e0 < a.k; e0 += 64) {
             const int e = e0 + lane;
             const bool valid = e < a.k;
