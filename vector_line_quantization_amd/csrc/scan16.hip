@@ -11,6 +11,8 @@
 //   * workgroups are dealt to XCDs so that queries adjacent in `qorder` (sorted by
 //     nearest coarse centroid) share an L2: their term2 rows and list codes are then
 //     mostly L2 hits instead of fabric reads.  Placement only affects speed.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
@@ -18,7 +20,7 @@
 
 namespace vlq {
 
-template <int KPL, int NW>
+template <int KPL, int NW, int NBUF>
 __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         const uint32_t pos0 = pm.cum[ik];
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + pm.poff[ik];
         float* L = lut + buf * E;
+        if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
         build_lut16<NI>(L, t, t2r, m2t3);
         uint4 cc = c0;
         const int nxt = prefetch(ik + 1);
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
             cc = cn;
         }
         nscan += len;
-        buf ^= 1;
+        if (NBUF == 2) buf ^= 1;
         ik = nxt;
     }
 
@@ -107,16 +110,16 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     if (badkey) *a.bad_key = 1;
 }
 
-template <int KPL, int NW>
+template <int KPL, int NW, int NBUF>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_kernel<KPL, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_smem = smem;
     }
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
-    hipLaunchKernelGGL((scan16_kernel<KPL, NW>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
+    hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
 
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
@@ -125,15 +128,18 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     a.xcd_chunk = (int)((a.nq + 7) / 8);
     // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
     // larger k keeps more selection state per wave, so stay at 4 waves
-    const int nw = a.k <= 64 ? 8 : 4;
-    size_t lutb = (size_t)2 * 4096 * 4;
+    const int nw = 4;
+    static const int nbuf = getenv("VLQ_EXP_NBUF") ? atoi(getenv("VLQ_EXP_NBUF")) : 2;
+    size_t lutb = (size_t)(a.k <= 64 ? nbuf : 2) * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
     const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 4 + 64;
     const size_t smem = lutb + tail;
-    if (a.k <= 64) launch_scan16_t<1, 8>(a, (int)lutb, smem, s);
-    else if (a.k <= 256) launch_scan16_t<4, 4>(a, (int)lutb, smem, s);
-    else launch_scan16_t<16, 4>(a, (int)lutb, smem, s);
+    if (a.k <= 64) {
+        if (nbuf == 1) launch_scan16_t<1, 4, 1>(a, (int)lutb, smem, s);
+        else launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
+    } else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
+    else launch_scan16_t<16, 4, 2>(a, (int)lutb, smem, s);
 }
 
 // ---------------------------------------------------------------------------
