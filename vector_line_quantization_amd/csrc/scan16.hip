@@ -11,8 +11,6 @@
 //   * workgroups are dealt to XCDs so that queries adjacent in `qorder` (sorted by
 //     nearest coarse centroid) share an L2: their term2 rows and list codes are then
 //     mostly L2 hits instead of fabric reads.  Placement only affects speed.
-#include <cstdlib>
-
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
@@ -128,17 +126,18 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     a.xcd_chunk = (int)((a.nq + 7) / 8);
     // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
     // larger k keeps more selection state per wave, so stay at 4 waves
+    // Measured alternatives (r01, MI355X, bench data): 8 waves per workgroup 0.95 ms, single
+    // LUT buffer with 6 workgroups per CU 0.78 ms, two probes of lookahead 0.82 ms, two
+    // queries per workgroup sharing term2 rows 0.93 ms -- against 0.78-0.82 ms for this
+    // configuration (4 waves, double-buffered LUT, one probe of lookahead).
     const int nw = 4;
-    static const int nbuf = getenv("VLQ_EXP_NBUF") ? atoi(getenv("VLQ_EXP_NBUF")) : 2;
-    size_t lutb = (size_t)(a.k <= 64 ? nbuf : 2) * 4096 * 4;
+    size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
     const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 4 + 64;
     const size_t smem = lutb + tail;
-    if (a.k <= 64) {
-        if (nbuf == 1) launch_scan16_t<1, 4, 1>(a, (int)lutb, smem, s);
-        else launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
-    } else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
+    if (a.k <= 64) launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
+    else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
     else launch_scan16_t<16, 4, 2>(a, (int)lutb, smem, s);
 }
 
