@@ -209,6 +209,15 @@ def main():
     code_bytes = ncode_per_launch * args.M           # B_scan = ncode * code_size
     achieved = code_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     lut_bytes = args.nq * args.nprobe * args.M * 256 * 4.0
+    # HBM traffic of the scan kernel per launch from the committed rocprofv3 PMC passes
+    # (profiles/pmc_passes.sh; FETCH_SIZE corrected x2 as the gfx950 guide prescribes)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
+    if os.path.exists(tpath) and args.nq == 10000 and args.nb == 1000000 and world == 1:
+        try:
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
 
     out = {
         "metric": "queries/sec @ recall@1 (SIFT1M, nlist=4096 m=16 nprobe=32 k=10)",
@@ -221,8 +230,8 @@ def main():
                    "parallelism": "index replicated, queries sharded x%d, all-gather of top-k" % world,
                    "list_imbalance": round(imb, 3), "ncode_per_query": ncode_per_launch / args.nq},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "scan_kernel", "kernel_ms": scan_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "vlq::scan16_kernel", "kernel_ms": scan_ms,
                      "algorithmic_bytes": code_bytes,
                      "lut_bytes_separate": lut_bytes,
                      "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0},

@@ -243,7 +243,6 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                                   table_mode == 1 ? 0 : 1, h->ws_qtab.as<float>(), h->stream);
             tm.stop();
         }
-        StageTimer tm(h, 2);
         vlq::ScanArgs a;
         a.codes = h->codes.as<uint8_t>();
         a.ids = h->ids.as<int64_t>();
@@ -269,18 +268,23 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
         if (fast16) {
             if (ni >= 1024) {
+                StageTimer tq(h, 1);   // query ordering is booked with the table stage
                 // run queries that share their nearest centroid next to each other (L2 reuse)
                 TRY(h->ws_hist.reserve(((size_t)h->nlist + 1) * sizeof(int)));
                 TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream);
                 a.qorder = h->ws_qorder.as<int>();
+                tq.stop();
             }
+            StageTimer tm(h, 2);       // exactly the scan kernel
             vlq::launch_scan16(a, h->stream);
+            tm.stop();
         } else {
+            StageTimer tm(h, 2);
             vlq::launch_scan(a, h->stream);
+            tm.stop();
         }
-        tm.stop();
     }
     HIP_TRY(hipGetLastError());
     h->stat_nq += (uint64_t)n;
