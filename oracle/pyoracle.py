@@ -26,8 +26,8 @@ class _OrcIndex(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "ivfpq_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ivfpq_oracle.cpp", "vlq_oracle.cpp")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
@@ -47,6 +47,7 @@ def lib():
         L.orc_search_knn_with_key.restype = C.c_int64
         L.orc_search.restype = C.c_int64
         L.orc_num_threads.restype = C.c_int
+        L.orc_vlq_search.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -225,3 +226,127 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(C.c_int(int(n)))
+
+
+# ---------------------------------------------------------------------------
+# VLQ (vector and line quantization) oracle -- PARITY UNPINNED, see vlq_oracle.cpp
+# ---------------------------------------------------------------------------
+class _OrcVlq(C.Structure):
+    _fields_ = [("d", C.c_int32), ("nlist", C.c_int32), ("M", C.c_int32), ("nbits", C.c_int32),
+                ("ksub", C.c_int32), ("dsub", C.c_int32), ("nedge", C.c_int32), ("nlambda", C.c_int32),
+                ("coarse", C.c_void_p), ("pq_centroids", C.c_void_p), ("edge_info", C.c_void_p),
+                ("edge_dist", C.c_void_p), ("lambda_info", C.c_void_p), ("term2", C.c_void_p),
+                ("codes", C.c_void_p), ("lambdas", C.c_void_p), ("ids", C.c_void_p),
+                ("line_off", C.c_void_p)]
+
+
+class OracleVLQ:
+    def __init__(self, d, nlist, M, nbits, nedge, nlambda, coarse, pq_centroids=None,
+                 edge_info=None, edge_dist=None, lambda_info=None):
+        self.d, self.nlist, self.M, self.nbits, self.nedge, self.nlambda = d, nlist, M, nbits, nedge, nlambda
+        self.ksub, self.dsub = 1 << nbits, d // M
+        self.coarse = _f32(coarse).reshape(nlist, d)
+        self.pq_centroids = None if pq_centroids is None else _f32(pq_centroids).reshape(M, self.ksub, self.dsub)
+        if edge_info is None:
+            edge_info = np.empty((nlist, nedge), np.int32)
+            edge_dist = np.empty((nlist, nedge), np.float32)
+            lib().orc_vlq_build_graph(_p(self.coarse), C.c_int(nlist), C.c_int(d), C.c_int(nedge),
+                                      _p(edge_info), _p(edge_dist))
+        self.edge_info = np.ascontiguousarray(edge_info, np.int32)
+        self.edge_dist = _f32(edge_dist)
+        self.lambda_info = None if lambda_info is None else _f32(lambda_info)
+        self.term2 = None
+        nl = nlist * nedge
+        self.codes = np.zeros((0, M), np.uint8)
+        self.lambdas = np.zeros((0,), np.uint8)
+        self.ids = np.zeros((0,), np.int64)
+        self.line_off = np.zeros((nl + 1,), np.int64)
+
+    def _c(self):
+        s = _OrcVlq()
+        s.d, s.nlist, s.M, s.nbits, s.ksub, s.dsub = self.d, self.nlist, self.M, self.nbits, self.ksub, self.dsub
+        s.nedge, s.nlambda = self.nedge, self.nlambda
+        s.coarse, s.pq_centroids = _p(self.coarse), _p(self.pq_centroids)
+        s.edge_info, s.edge_dist, s.lambda_info = _p(self.edge_info), _p(self.edge_dist), _p(self.lambda_info)
+        s.term2 = _p(self.term2)
+        s.codes, s.lambdas, s.ids, s.line_off = _p(self.codes), _p(self.lambdas), _p(self.ids), _p(self.line_off)
+        return s
+
+    def nearest(self, x):
+        x = _f32(x).reshape(-1, self.d)
+        D = np.empty((x.shape[0], 1), np.float32)
+        I = np.empty((x.shape[0], 1), np.int64)
+        lib().orc_knn_L2sqr(_p(x), _p(self.coarse), C.c_size_t(self.d), C.c_size_t(x.shape[0]),
+                            C.c_size_t(self.nlist), C.c_size_t(1), _p(D), _p(I), C.c_int(1), C.c_int(2))
+        return I[:, 0].copy()
+
+    def assign(self, x):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        near = self.nearest(x)
+        line = np.empty((n,), np.int32)
+        lam = np.empty((n,), np.float32)
+        s = self._c()
+        lib().orc_vlq_assign(C.byref(s), _p(x), C.c_size_t(n), _p(near), _p(line), _p(lam))
+        return line, lam
+
+    def quantize_lambda(self, lam):
+        lam = _f32(lam)
+        out = np.empty(lam.shape, np.uint8)
+        s = self._c()
+        lib().orc_vlq_quantize_lambda(C.byref(s), _p(lam), C.c_size_t(lam.shape[0]), _p(out))
+        return out
+
+    def residuals(self, x, line, lam_byte):
+        x = _f32(x).reshape(-1, self.d)
+        out = np.empty_like(x)
+        s = self._c()
+        lib().orc_vlq_residuals(C.byref(s), _p(x), C.c_size_t(x.shape[0]),
+                                _p(np.ascontiguousarray(line, np.int32)),
+                                _p(np.ascontiguousarray(lam_byte, np.uint8)), _p(out))
+        return out
+
+    def encode(self, x):
+        line, lam = self.assign(x)
+        lb = self.quantize_lambda(lam)
+        res = self.residuals(x, line, lb)
+        codes = np.empty((res.shape[0], self.M), np.uint8)
+        s = self._c()
+        lib().orc_vlq_pq_encode(C.byref(s), _p(res), C.c_size_t(res.shape[0]), _p(codes))
+        return line, lb, codes
+
+    def set_term2(self):
+        ix = OracleIndex(self.d, self.nlist, self.M, self.nbits, self.coarse, self.pq_centroids)
+        self.term2 = ix.precomputed_table
+
+    def add(self, x, xids=None):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        nt = self.ids.shape[0]
+        if xids is None:
+            xids = np.arange(nt, nt + n, dtype=np.int64)
+        line, lb, codes = self.encode(x)
+        old_line = np.repeat(np.arange(self.nlist * self.nedge), np.diff(self.line_off))
+        al = np.concatenate([old_line, line.astype(np.int64)])
+        keep = al >= 0
+        order = np.argsort(al[keep], kind="stable")
+        self.codes = np.ascontiguousarray(np.concatenate([self.codes, codes])[keep][order])
+        self.lambdas = np.ascontiguousarray(np.concatenate([self.lambdas, lb])[keep][order])
+        self.ids = np.ascontiguousarray(np.concatenate([self.ids, np.asarray(xids, np.int64)])[keep][order])
+        cnt = np.bincount(al[keep], minlength=self.nlist * self.nedge)
+        self.line_off = np.zeros(self.nlist * self.nedge + 1, np.int64)
+        np.cumsum(cnt, out=self.line_off[1:])
+        return line, lb, codes
+
+    def search(self, x, nprobe, w1, k, return_lines=False):
+        x = _f32(x).reshape(-1, self.d)
+        n = x.shape[0]
+        if self.term2 is None:
+            self.set_term2()
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        lines = np.empty((n, w1), np.int32)
+        s = self._c()
+        self.last_ncode = int(lib().orc_vlq_search(C.byref(s), _p(x), C.c_size_t(n), C.c_int(nprobe),
+                                                   C.c_int(w1), C.c_int(k), _p(D), _p(I), _p(lines)))
+        return (D, I, lines) if return_lines else (D, I)
