@@ -1,0 +1,78 @@
+/*
+ * vlq_line.h -- C ABI of the fork's "vector and line quantization" (VLQ) index on
+ * MI355X: the path behind the reference's
+ *   GpuIndexIVFPQ(resources, dims, nlist, subQuantizers, bitsPerCode, nedge, nLambda,
+ *                 metric, config)                      gpu/GpuIndexIVFPQ.h:60-68
+ * i.e. train / buildGraph_ / classifyAndAddVectors / searchImpl_ -> IVFPQ::queryGraph
+ * (gpu/GpuIndexIVFPQ.cu:346-403, :577-908, :1400-1460; gpu/impl/IVFPQ.cu:685-775).
+ *
+ * Data model: coarse centroids c_i with a k-NN graph (`nedge` edges per centroid); a
+ * vector lives on line id = i*nedge + e (from c_i towards s = edge_info[i][e]) with a
+ * one-byte index into the scalar codebook lambda_info[nlambda] and an M-byte PQ code
+ * of its residual to the anchor (1-l) c_i + l s.  Lines are the inverted lists.
+ *
+ * Same conventions as vlq_ivfpq.h ([h|d] pointers, status codes, vlq_last_error()).
+ * Returned distances omit |q|^2 exactly as the fork's search does
+ * (gpu/impl/Distance.cu:286-291): D = |q - y|^2 - |q|^2.
+ */
+#ifndef VLQ_LINE_H
+#define VLQ_LINE_H
+
+#include "vlq_ivfpq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vlq_line_s* vlq_line_t;
+
+#define VLQ_LINE_MAX_CODES 1024   /* codes visited per line, PQScanMultiPassPrecomputed.cu:728 */
+
+int vlq_line_create(vlq_line_t* out, int device, int d, int nlist, int M, int nbits, int nedge,
+                    int nlambda);
+void vlq_line_destroy(vlq_line_t h);
+int vlq_line_set_stream(vlq_line_t h, void* hip_stream);
+
+/* trained state (GpuIndexIVFPQ::readCodebookFromFile layout: centroids | pq | edgeInfo |
+ * edgeDistInfo | lambdaInfo, gpu/GpuIndexIVFPQ.cu:1731-1758).  All [h|d]. */
+int vlq_line_set_coarse_centroids(vlq_line_t h, const float* centroids);      /* [nlist*d] */
+int vlq_line_set_pq_centroids(vlq_line_t h, const float* centroids);          /* [M][ksub][dsub] */
+int vlq_line_set_lambda_codebook(vlq_line_t h, const float* lambda_info);     /* [nlambda] */
+int vlq_line_set_graph(vlq_line_t h, const int32_t* edge_info, const float* edge_dist); /* [nlist*nedge] */
+/* GpuIndexFlat::buildGraph (gpu/GpuIndexFlat.cu:375-429,869-893): nedge nearest other
+ * centroids of every centroid, on the device.  Outputs optional host buffers. */
+int vlq_line_build_graph(vlq_line_t h, int32_t* edge_info_out, float* edge_dist_out);
+
+/* training primitives (trainResidualQuantizer_, gpu/GpuIndexIVFPQ.cu:346-403):
+ *   assign   : nearest centroid + best line + real-valued lambda (get1BinKernel_nms)
+ *   residuals: x - ((1-l) c + l s) with l = lambda_info[quantised lambda] (calResidual)
+ * x [h|d]; outputs host buffers. */
+int vlq_line_assign(vlq_line_t h, int64_t n, const float* x, int32_t* line_id, float* lambdaf);
+int vlq_line_residuals(vlq_line_t h, int64_t n, const float* x, float* residuals);
+/* full encoding: line id, lambda byte, PQ code (classifyAndAddVectors :577-908) */
+int vlq_line_encode(vlq_line_t h, int64_t n, const float* x, int32_t* line_id, uint8_t* lambda,
+                    uint8_t* codes);
+
+/* add_with_ids (addImpl_ -> classifyAndAddVectors); xids may be NULL */
+int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids);
+/* bulk load, line-contiguous (readDbFromFile: .dbcodes / .dblas / .dbIdx / .dbcount,
+ * gpu/GpuIndexIVFPQ.cu:1813-1844): codes[ntotal][M], lambdas[ntotal], ids[ntotal],
+ * line_offsets[nlist*nedge+1].  [h|d] */
+int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambdas,
+                       const int64_t* ids, const int64_t* line_offsets);
+int64_t vlq_line_ntotal(vlq_line_t h);
+int vlq_line_list_length(vlq_line_t h, int64_t line, int64_t* len);
+int vlq_line_get_list(vlq_line_t h, int64_t line, uint8_t* codes_out, uint8_t* lambdas_out,
+                      int64_t* ids_out);
+
+/* GpuIndexIVFPQ::search with nprobe_ coarse centroids and w1_ lines kept per query
+ * (queryGraph).  nprobe <= 1024, w1 <= 1024, k <= 1024.  x, D, I [h|d].
+ * lines_out (optional, host, [n*w1]): the selected line ids in selection order. */
+int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1, int k, float* D,
+                    int64_t* I, int32_t* lines_out);
+int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLQ_LINE_H */

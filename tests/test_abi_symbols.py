@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "vlq_ivfpq.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(vlq_[a-z0-9_]+)\s*\(", txt)))
+    syms = set()
+    for hdr in ("vlq_ivfpq.h", "vlq_line.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(vlq_[a-z0-9_]+)\s*\(", txt))
+    return sorted(syms)
 
 
 def test_header_and_loader_agree():

@@ -1,0 +1,120 @@
+"""GPU: the VLQ (vector and line quantization) path through the C ABI of
+include/vlq_line.h against the VLQ oracle.  The oracle itself is PARITY UNPINNED
+against the reference binary (CUDA-only path, see oracle/vlq_oracle.cpp) and is held
+to independent float64 recomputations in tests/test_vlq_oracle.py; here the HIP path
+must reproduce the oracle bit for bit."""
+import numpy as np
+import pytest
+
+import vector_line_quantization_amd as vlq
+from test_vlq_oracle import decode, make_vlq
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_from_oracle(v, with_lists=True, graph=True):
+    g = vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, v.nedge, v.nlambda)
+    g.set_coarse_centroids(v.coarse)
+    if graph:
+        g.set_graph(v.edge_info, v.edge_dist)
+    g.set_lambda_codebook(v.lambda_info)
+    g.set_pq_centroids(v.pq_centroids)
+    if with_lists:
+        g.set_lists(v.codes, v.lambdas, v.ids, v.line_off)
+    return g
+
+
+@pytest.fixture(scope="module")
+def world():
+    return make_vlq()
+
+
+def test_graph_build_matches_oracle(world):
+    v, _, _ = world
+    g = gpu_from_oracle(v, with_lists=False, graph=False)
+    ei, ed = g.build_graph()
+    assert np.array_equal(ei, v.edge_info)
+    assert np.array_equal(bits(ed), bits(v.edge_dist))
+
+
+def test_assign_and_encode_match_oracle(world):
+    v, xb, _ = world
+    g = gpu_from_oracle(v, with_lists=False)
+    line, lam = g.assign(xb)
+    lo, lamo = v.assign(xb)
+    assert np.array_equal(line, lo)
+    assert np.array_equal(bits(lam), bits(lamo))
+    lb = v.quantize_lambda(lamo)
+    assert np.array_equal(bits(g.residuals(xb)), bits(v.residuals(xb, lo, lb)))
+    l2, lb2, codes = g.encode(xb)
+    lo2, lbo, co = v.encode(xb)
+    assert np.array_equal(l2, lo2) and np.array_equal(lb2, lbo) and np.array_equal(codes, co)
+
+
+def test_add_builds_the_same_lines(world):
+    v, xb, _ = world
+    g = gpu_from_oracle(v, with_lists=False)
+    g.add(xb[:1500])
+    g.add(xb[1500:])
+    assert g.ntotal == v.ids.shape[0]
+    for line in range(v.nlist * v.nedge):
+        c, l, i = g.get_list(line)
+        o0, o1 = v.line_off[line], v.line_off[line + 1]
+        assert np.array_equal(i, v.ids[o0:o1]) and np.array_equal(c, v.codes[o0:o1]) and np.array_equal(l, v.lambdas[o0:o1])
+
+
+@pytest.mark.parametrize("nprobe,w1,k", [(8, 24, 10), (4, 1, 1), (24, 144, 100), (6, 30, 300), (24, 64, 64)])
+def test_search_bit_exact_vs_oracle(world, nprobe, w1, k):
+    v, _, xq = world
+    g = gpu_from_oracle(v)
+    D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
+    Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    assert g.stats(reset=True) == v.last_ncode
+
+
+def test_search_distances_are_true_distances_minus_query_norm(world):
+    v, _, xq = world
+    g = gpu_from_oracle(v)
+    D, I = g.search(xq, 8, 24, 5)
+    pos_of = {int(i): p for p, i in enumerate(v.ids)}
+    for qi in range(10):
+        q = xq[qi].astype(np.float64)
+        for j in range(5):
+            y = decode(v, pos_of[int(I[qi, j])])
+            ref = ((q - y) ** 2).sum() - (q ** 2).sum()
+            assert abs(D[qi, j] - ref) <= 1e-3 * max(1.0, abs(ref))
+
+
+def test_line_cap_1024_codes():
+    """Lines are scanned up to 1024 codes (PQScanMultiPassPrecomputed.cu:728)."""
+    v, xb, xq = make_vlq(seed=3, nlist=4, nedge=2, nb=6000)
+    assert np.diff(v.line_off).max() > 1024
+    g = gpu_from_oracle(v)
+    D, I = g.search(xq, 4, 8, 20)
+    Do, Io = v.search(xq, 4, 8, 20)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    assert g.stats() == v.last_ncode < xq.shape[0] * 6000
+
+
+def test_m16_8bit_d128_shape():
+    """The 16-byte-code shape of the reference's deep1b16 / sift1b16 drivers."""
+    v, xb, xq = make_vlq(seed=5, d=128, nlist=32, M=16, nbits=8, nedge=8, nlambda=64, nb=4000)
+    g = gpu_from_oracle(v)
+    D, I = g.search(xq, 8, 32, 10)
+    Do, Io = v.search(xq, 8, 32, 10)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
+def test_error_paths(world):
+    v, _, xq = world
+    g = vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, v.nedge, v.nlambda)
+    with pytest.raises(vlq.VlqError):
+        g.search(xq, 4, 8, 5)            # nothing trained
+    with pytest.raises(vlq.VlqError):
+        vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, v.nlist, 16)     # nedge >= nlist
+    with pytest.raises(vlq.VlqError):
+        vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, 4, 300)          # lambda index does not fit a byte

@@ -6,6 +6,6 @@ bench.py and the multi-GPU driver.  There is no CPU implementation in here: if
 the library is missing or no HIP device is present, calls fail loudly.
 """
 from ._lib import VlqError, build_library, device_count, lib, library_path  # noqa: F401
-from .index import GpuIVFPQ  # noqa: F401
+from .index import GpuIVFPQ, GpuVLQ  # noqa: F401
 
-__all__ = ["GpuIVFPQ", "VlqError", "build_library", "device_count", "lib", "library_path"]
+__all__ = ["GpuIVFPQ", "GpuVLQ", "VlqError", "build_library", "device_count", "lib", "library_path"]

@@ -18,6 +18,12 @@ SYMBOLS = [
     "vlq_ivfpq_search_preassigned", "vlq_ivfpq_coarse_search", "vlq_ivfpq_query_tables",
     "vlq_ivfpq_get_precomputed_table", "vlq_ivfpq_stats", "vlq_ivfpq_profile",
     "vlq_ivfpq_profile_read",
+    # include/vlq_line.h
+    "vlq_line_create", "vlq_line_destroy", "vlq_line_set_stream", "vlq_line_set_coarse_centroids",
+    "vlq_line_set_pq_centroids", "vlq_line_set_lambda_codebook", "vlq_line_set_graph",
+    "vlq_line_build_graph", "vlq_line_assign", "vlq_line_residuals", "vlq_line_encode", "vlq_line_add",
+    "vlq_line_set_lists", "vlq_line_ntotal", "vlq_line_list_length", "vlq_line_get_list",
+    "vlq_line_search", "vlq_line_stats",
 ]
 
 
@@ -75,6 +81,8 @@ def lib():
         L.vlq_last_error.restype = C.c_char_p
         L.vlq_ivfpq_ntotal.restype = C.c_int64
         L.vlq_ivfpq_destroy.restype = None
+        L.vlq_line_ntotal.restype = C.c_int64
+        L.vlq_line_destroy.restype = None
         _lib = L
     return _lib
 

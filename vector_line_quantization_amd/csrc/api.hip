@@ -1,107 +1,9 @@
 // C ABI (include/vlq_ivfpq.h) over the HIP kernels.  Host-side orchestration only:
 // device buffers, workspace, paging of large query batches, host<->device staging.
 // No CPU compute path exists here: every search/add entry point launches kernels.
-#include "../../include/vlq_ivfpq.h"
-#include "kernels.h"
+#include "handle.h"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                    \
-    do {                                                                                 \
-        hipError_t e_ = (expr);                                                          \
-        if (e_ != hipSuccess)                                                            \
-            return fail(VLQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                             \
-    } while (0)
-
-#define TRY(expr)                 \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_ != VLQ_OK) return rc_; \
-    } while (0)
-
-// growable device buffer
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return VLQ_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            e = hipMalloc(&p, bytes);
-            want = bytes;
-        }
-        if (e != hipSuccess) { p = nullptr; return fail(VLQ_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-        cap = want;
-        return VLQ_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-bool is_device_ptr(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t attr;
-    hipError_t e = hipPointerGetAttributes(&attr, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
-}
-
-}  // namespace
-
-struct vlq_ivfpq_s {
-    int device = 0, d = 0, nlist = 0, M = 0, nbits = 0, ksub = 0, dsub = 0;
-    int by_residual = 1, use_precomputed_table = 1;
-    int64_t max_codes = 0;
-    int64_t ntotal = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-
-    DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off;
-    bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
-    std::vector<int64_t> h_list_off;
-
-    // workspace
-    DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
-        ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder;
-    DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
-    uint64_t stat_nq = 0;
-
-    // profiling
-    bool prof = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    struct Pending { hipEvent_t a, b; int stage; };
-    std::vector<Pending> pending;
-    std::vector<hipEvent_t> ev_pool;
-    double prof_ms[3] = {0, 0, 0};
-    int64_t prof_calls = 0;
-};
-
-namespace {
+namespace vlq_detail {
 
 int set_dev(vlq_ivfpq_t h) {
     HIP_TRY(hipSetDevice(h->device));
@@ -193,6 +95,27 @@ int64_t query_page(vlq_ivfpq_t h) {
     return page;
 }
 
+// coarse stage of one page; the [n][nlist] distance matrix stays in h->ws_dist
+int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
+                int64_t* keys_dev, bool zero_qnorm, bool direct) {
+    TRY(h->ws_qn.reserve((size_t)n * sizeof(float)));
+    TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
+    if (direct) {
+        vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
+                                            h->nlist, h->d, h->stream);
+    } else {
+        if (zero_qnorm) HIP_TRY(hipMemsetAsync(h->ws_qn.p, 0, (size_t)n * sizeof(float), h->stream));
+        else vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
+        vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(),
+                                     h->cnorm.as<float>(), h->ws_dist.as<float>(), n, h->nlist,
+                                     h->d, h->stream);
+    }
+    vlq::launch_coarse_select(h->ws_dist.as<float>(), n, h->nlist, nprobe, cdis_dev, keys_dev,
+                              h->stream);
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
 // coarse stage on device buffers: x_dev [n][d] -> cdis_dev, keys_dev [n][nprobe]
 int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
                int64_t* keys_dev) {
@@ -200,24 +123,11 @@ int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* 
     const int64_t page = query_page(h);
     // knn_L2sqr dispatch (utils.cpp:935-946): small batches bypass the GEMM formulation
     const bool direct = (h->d % 4 == 0) && n < 20;
-    TRY(h->ws_qn.reserve((size_t)std::min(n, page) * sizeof(float)));
-    TRY(h->ws_dist.reserve((size_t)std::min(n, page) * h->nlist * sizeof(float)));
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
-        const float* xi = x_dev + i0 * h->d;
-        if (direct) {
-            vlq::launch_coarse_distances_direct(xi, h->coarse.as<float>(), h->ws_dist.as<float>(),
-                                                ni, h->nlist, h->d, h->stream);
-        } else {
-            vlq::launch_row_norms(xi, ni, h->d, h->ws_qn.as<float>(), h->stream);
-            vlq::launch_coarse_distances(xi, h->coarse.as<float>(), h->ws_qn.as<float>(),
-                                         h->cnorm.as<float>(), h->ws_dist.as<float>(), ni,
-                                         h->nlist, h->d, h->stream);
-        }
-        vlq::launch_coarse_select(h->ws_dist.as<float>(), ni, h->nlist, nprobe,
-                                  cdis_dev + i0 * nprobe, keys_dev + i0 * nprobe, h->stream);
+        TRY(coarse_page(h, ni, x_dev + i0 * h->d, nprobe, cdis_dev + i0 * nprobe,
+                        keys_dev + i0 * nprobe, false, direct));
     }
-    HIP_TRY(hipGetLastError());
     tm.stop();
     return VLQ_OK;
 }
@@ -322,7 +232,7 @@ extern "C" {
 
 int vlq_version(void) { return 100; }
 
-const char* vlq_last_error(void) { return g_err.c_str(); }
+const char* vlq_last_error(void) { return err_slot().c_str(); }
 
 int vlq_device_count(void) {
     int n = 0;

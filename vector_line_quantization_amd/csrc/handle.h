@@ -1,0 +1,118 @@
+// Internal: the index handle and small host helpers shared by api.hip and line_api.hip.
+#pragma once
+#include "../../include/vlq_ivfpq.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace vlq_detail {
+
+inline std::string& err_slot() { static thread_local std::string s; return s; }
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err_slot() = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(VLQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != VLQ_OK) return rc_; \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return VLQ_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e != hipSuccess) { p = nullptr; return fail(VLQ_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = want;
+        return VLQ_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+}  // namespace vlq_detail
+using namespace vlq_detail;
+
+struct vlq_ivfpq_s {
+    int device = 0, d = 0, nlist = 0, M = 0, nbits = 0, ksub = 0, dsub = 0;
+    int by_residual = 1, use_precomputed_table = 1;
+    int64_t max_codes = 0;
+    int64_t ntotal = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off;
+    bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
+    std::vector<int64_t> h_list_off;
+
+    // workspace
+    DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
+        ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder;
+    DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
+    uint64_t stat_nq = 0;
+
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    struct Pending { hipEvent_t a, b; int stage; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_calls = 0;
+};
+
+
+// internal entry points implemented in api.hip
+namespace vlq_detail {
+int set_dev(vlq_ivfpq_t h);
+int stage_in(vlq_ivfpq_t h, const void* src, size_t bytes, DevBuf& ws, const void** out);
+int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy);
+int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t bytesD, bool copyI,
+                   void* I, const void* Id, size_t bytesI);
+int ensure_term2(vlq_ivfpq_t h);
+int64_t query_page(vlq_ivfpq_t h);
+// coarse stage of ONE page (n <= query_page): leaves the [n][nlist] distance matrix in
+// h->ws_dist; zero_qnorm drops |q|^2 (the VLQ path, impl/Distance.cu:286-291)
+int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
+                int64_t* keys_dev, bool zero_qnorm, bool direct);
+}  // namespace vlq_detail

@@ -1,0 +1,40 @@
+// Host-side launch interface of the VLQ kernels (line.hip).
+#pragma once
+#include "kernels.h"
+
+namespace vlq {
+
+void launch_line_assign(const float* x, int64_t n, int d, const float* coarse, const int64_t* nearest,
+                        const int32_t* edge_info, const float* edge_dist, int nedge, int32_t* line_id,
+                        float* lambdaf, hipStream_t s);
+void launch_lambda_quantize(const float* lambdaf, int64_t n, const float* lambda_info, int nlambda,
+                            uint8_t* out, hipStream_t s);
+void launch_line_residuals(const float* x, int64_t n, int d, const float* coarse, const int32_t* edge_info,
+                           int nedge, const int32_t* line_id, const uint8_t* lambda,
+                           const float* lambda_info, float* res, hipStream_t s);
+void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,
+                        const int32_t* edge_info, const float* edge_dist, int nedge, int w1,
+                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s);
+
+struct LineScanArgs {
+    const uint8_t* codes;        // [ntotal][M] line-contiguous
+    const uint8_t* lambdas;      // [ntotal]
+    const int64_t* ids;          // [ntotal]
+    const int64_t* line_off;     // [nlist*nedge + 1]
+    const float* term2;          // [nlist][M*ksub]
+    const float* qtab;           // [nq][M*ksub]  <q_m, cent_mj>
+    const int32_t* edge_info;    // [nlist*nedge]
+    const float* edge_dist;      // [nlist*nedge]
+    const float* lambda_info;    // [nlambda]
+    const int32_t* sel_line;     // [nq][w1]
+    const float* sel_b2;         // [nq][w1]
+    const float* sel_g;          // [nq][w1]
+    float* D;
+    int64_t* I;
+    unsigned long long* ncode;
+    int64_t nq;
+    int w1, k, M, ksub, nedge, max_line_codes;
+};
+void launch_line_scan(const LineScanArgs& a, hipStream_t s);
+
+}  // namespace vlq

@@ -1,0 +1,334 @@
+// HIP kernels of the VLQ (vector and line quantization) path for gfx950.
+//
+// Stage map (reference CUDA kernel -> kernel here), arithmetic as fixed by
+// oracle/vlq_oracle.cpp (the reference leaves operation order / ties to nvcc and to
+// unstable sorts; see that file's header):
+//   get1BinKernel_nms        gpu/GpuIndexFlat.cu:433-557         -> line_assign_kernel
+//   assignLambdaKernel       gpu/GpuIndexFlat.cu:559-602         -> lambda_quantize_kernel
+//   calResidual              gpu/GpuIndexFlat.cu:1092-1129        -> line_residual_kernel
+//   sumAlongRowsWithOrder2   gpu/impl/BroadcastSum.cu:477-560     -> line_select_kernel
+//   pqScanPrecomputedMultiPassGraph + pass1/pass2 select
+//                            gpu/impl/PQScanMultiPassPrecomputed.cu:675-811,
+//                            IVFUtilsSelect1.cu, IVFUtilsSelect2.cu:398-569 -> line_scan_kernel
+#include "line.h"
+#include "scan_common.cuh"
+#include "sse_order.cuh"
+#include "wave_topk.cuh"
+
+namespace vlq {
+
+#define FLT_MAX_F 3.402823466e+38f
+
+// ---------------------------------------------------------------------------
+// line assignment: one wave per vector, lanes over the edges of its nearest centroid
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void line_assign_kernel(
+    const float* __restrict__ x, int64_t n, int d, const float* __restrict__ coarse,
+    const int64_t* __restrict__ nearest, const int32_t* __restrict__ edge_info,
+    const float* __restrict__ edge_dist, int nedge, int32_t* __restrict__ line_id,
+    float* __restrict__ lambdaf) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][d]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+    if (v >= n) return;
+    const int64_t A = nearest[v];
+    if (A < 0) { if (lane == 0) { line_id[v] = -1; lambdaf[v] = 0.f; } return; }
+    float* xs = sm + wave * d;
+    for (int c = lane; c < d; c += 64) xs[c] = x[v * d + c];
+    __builtin_amdgcn_wave_barrier();
+    const float* ca = coarse + A * d;
+    const float b2 = l2sqr_sse_order([&](int c) { return xs[c]; }, [&](int c) { return ca[c]; }, d);
+    // per lane: best edge overall and best edge with 0 <= lambda <= 1, ties to the lowest edge
+    int be = -1, bi = -1;
+    float bd = 0.f, bl = 0.f, bdi = 0.f, bli = 0.f;
+    for (int e = lane; e < nedge; e += 64) {
+        const int s = edge_info[A * nedge + e];
+        const float* cs = coarse + (int64_t)s * d;
+        const float a2 = l2sqr_sse_order([&](int c) { return xs[c]; }, [&](int c) { return cs[c]; }, d);
+        const float c2 = edge_dist[A * nedge + e];
+        const float amb = __fsub_rn(__fsub_rn(a2, b2), c2);                 // a2 - b2 - c2
+        const float l = __fdiv_rn(__fmul_rn(-0.5f, amb), c2);               // project(), triangle.cuh:86-87
+        const float d2 = __fadd_rn(__fadd_rn(b2, __fmul_rn(__fmul_rn(l, l), c2)), __fmul_rn(l, amb));   // dist2()
+        if (be < 0 || d2 < bd) { be = e; bd = d2; bl = l; }
+        if (l >= 0.f && l <= 1.f && (bi < 0 || d2 < bdi)) { bi = e; bdi = d2; bli = l; }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        int oe = __shfl_xor(be, sft, 64);
+        float od = __shfl_xor(bd, sft, 64), ol = __shfl_xor(bl, sft, 64);
+        if (oe >= 0 && (be < 0 || od < bd || (od == bd && oe < be))) { be = oe; bd = od; bl = ol; }
+        oe = __shfl_xor(bi, sft, 64);
+        od = __shfl_xor(bdi, sft, 64);
+        ol = __shfl_xor(bli, sft, 64);
+        if (oe >= 0 && (bi < 0 || od < bdi || (od == bdi && oe < bi))) { bi = oe; bdi = od; bli = ol; }
+    }
+    if (lane == 0) {
+        const int e = bi >= 0 ? bi : be;
+        line_id[v] = (int32_t)(A * nedge + e);
+        lambdaf[v] = bi >= 0 ? bli : bl;
+    }
+}
+
+void launch_line_assign(const float* x, int64_t n, int d, const float* coarse, const int64_t* nearest,
+                        const int32_t* edge_info, const float* edge_dist, int nedge, int32_t* line_id,
+                        float* lambdaf, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(line_assign_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256),
+                       (size_t)4 * d * sizeof(float), s, x, n, d, coarse, nearest, edge_info, edge_dist,
+                       nedge, line_id, lambdaf);
+}
+
+// nearest scalar of the codebook, first minimum
+__global__ void lambda_quantize_kernel(const float* __restrict__ lambdaf, int64_t n,
+                                       const float* __restrict__ lambda_info, int nlambda,
+                                       uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = lambdaf[i];
+    int bi = 0;
+    float bd = FLT_MAX_F;
+    for (int j = 0; j < nlambda; j++) {
+        const float t = __fsub_rn(v, lambda_info[j]);
+        const float dd = __fmul_rn(t, t);
+        if (dd < bd) { bd = dd; bi = j; }
+    }
+    out[i] = (uint8_t)bi;
+}
+
+void launch_lambda_quantize(const float* lambdaf, int64_t n, const float* lambda_info, int nlambda,
+                            uint8_t* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lambda_quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       lambdaf, n, lambda_info, nlambda, out);
+}
+
+// x - ((1-l) c_A + l c_s)
+__global__ void line_residual_kernel(const float* __restrict__ x, int64_t n, int d,
+                                     const float* __restrict__ coarse,
+                                     const int32_t* __restrict__ edge_info, int nedge,
+                                     const int32_t* __restrict__ line_id,
+                                     const uint8_t* __restrict__ lambda,
+                                     const float* __restrict__ lambda_info, float* __restrict__ res) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * d) return;
+    const int64_t i = e / d;
+    const int j = (int)(e % d);
+    const int32_t line = line_id[i];
+    if (line < 0) { res[e] = 0.f; return; }
+    const int A = line / nedge;
+    const int s = edge_info[line];
+    const float la = lambda_info[lambda[i]];
+    const float oml = __fsub_rn(1.f, la);
+    const float anchor = __fadd_rn(__fmul_rn(oml, coarse[(int64_t)A * d + j]), __fmul_rn(la, coarse[(int64_t)s * d + j]));
+    res[e] = __fsub_rn(x[e], anchor);
+}
+
+void launch_line_residuals(const float* x, int64_t n, int d, const float* coarse, const int32_t* edge_info,
+                           int nedge, const int32_t* line_id, const uint8_t* lambda,
+                           const float* lambda_info, float* res, hipStream_t s) {
+    if (n <= 0) return;
+    const int64_t tot = n * d;
+    hipLaunchKernelGGL(line_residual_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, n,
+                       d, coarse, edge_info, nedge, line_id, lambda, lambda_info, res);
+}
+
+// ---------------------------------------------------------------------------
+// line select: one wave per query over the nprobe x nedge candidate lines
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void line_select_kernel(
+    const float* __restrict__ dist, int64_t nq, int nlist, const int64_t* __restrict__ keys,
+    int nprobe, const int32_t* __restrict__ edge_info, const float* __restrict__ edge_dist, int nedge,
+    int w1, int32_t* __restrict__ sel_line, float* __restrict__ sel_b2, float* __restrict__ sel_g) {
+    __shared__ u64 queue[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    WaveSelect<KPL> sel;
+    sel.init(w1, queue[wave], lane);
+    const float* row = dist + q * nlist;
+    const int64_t* kq = keys + q * nprobe;
+    const int num = nprobe * nedge;
+    for (int i0 = 0; i0 < num; i0 += 64) {
+        const int i = i0 + lane;
+        bool valid = i < num;
+        float key = 0.f;
+        if (valid) {
+            const int64_t c = kq[i / nedge];
+            valid = c >= 0;
+            if (valid) {
+                const int e = i % nedge;
+                const int s = edge_info[c * nedge + e];
+                const float a2 = row[s], b2 = row[c], c2 = edge_dist[c * nedge + e];
+                const float g = __fsub_rn(a2, b2);
+                const float t = __fsub_rn(g, c2);
+                // BroadcastSum.cu:503-507: beyond the near end -> distance to c, else to the line
+                key = (t > 0.f) ? b2 : __fsub_rn(b2, __fdiv_rn(__fmul_rn(__fmul_rn(0.25f, t), t), c2));
+            }
+        }
+        sel.offer(key, (uint32_t)i, valid);
+    }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int w = r * 64 + lane;
+        if (w >= w1) continue;
+        const u64 k64 = sel.best[r];
+        int32_t line = -1;
+        float b2 = 0.f, g = 0.f;
+        if (k64 != kMaxKey) {
+            const int i = (int)(uint32_t)k64;
+            const int64_t c = kq[i / nedge];
+            const int e = i % nedge;
+            const int s = edge_info[c * nedge + e];
+            line = (int32_t)(c * nedge + e);
+            b2 = row[c];
+            g = __fsub_rn(row[s], b2);
+        }
+        sel_line[q * w1 + w] = line;
+        sel_b2[q * w1 + w] = b2;
+        sel_g[q * w1 + w] = g;
+    }
+}
+
+void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,
+                        const int32_t* edge_info, const float* edge_dist, int nedge, int w1,
+                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s) {
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+#define VLQ_LS(K) hipLaunchKernelGGL(line_select_kernel<K>, grid, block, 0, s, dist, nq, nlist, keys, nprobe, \
+                                     edge_info, edge_dist, nedge, w1, sel_line, sel_b2, sel_g)
+    if (w1 <= 64) VLQ_LS(1);
+    else if (w1 <= 256) VLQ_LS(4);
+    else VLQ_LS(16);
+#undef VLQ_LS
+}
+
+// ---------------------------------------------------------------------------
+// line scan: one 256-thread workgroup per query walks its selected lines.  Per line
+// (c, s): two LUTs in LDS,  T23 = term2[c] + (-2 <q, cent>)  and  T4 = term2[s] - term2[c],
+// then per code (lambda l from the one-byte codebook)
+//    dist = ((b2 + l*g) + (l*l - l)*c2) + sum T23 + l * sum T4
+// (PQScanMultiPassPrecomputed.cu:744-811), at most 1024 codes per line (:728), running
+// top-k by (dist, scan position) as in the IVFPQ scan.
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_region) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int E = a.M * a.ksub;
+    float* t23 = reinterpret_cast<float*>(smraw);                    // [E]
+    float* t4 = t23 + E;                                             // [E]
+    u64* queue = reinterpret_cast<u64*>(smraw + lut_region);         // [4][64]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t q = blockIdx.x;
+    const int32_t* lq = a.sel_line + q * a.w1;
+    const float* qt = a.qtab + q * E;            // <q_m, cent_mj>; T3 = -2 * this
+
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    uint32_t pos0 = 0;
+    uint64_t nscan = 0;
+    for (int w = 0; w < a.w1; w++) {
+        const int32_t line = lq[w];
+        if (t == 0) cum[w] = pos0;
+        if (line < 0) continue;
+        const int64_t off = a.line_off[line];
+        int64_t len = a.line_off[line + 1] - off;
+        if (len > a.max_line_codes) len = a.max_line_codes;
+        if (len <= 0) continue;
+        const int c = line / a.nedge;
+        const int s = a.edge_info[line];
+        const float c2 = a.edge_dist[line];
+        const float b2 = a.sel_b2[q * a.w1 + w], g = a.sel_g[q * a.w1 + w];
+        const float* t2c = a.term2 + (size_t)c * E;
+        const float* t2s = a.term2 + (size_t)s * E;
+        __syncthreads();                         // previous line fully scanned
+        for (int e = t; e < E; e += 256) {
+            const float vc = t2c[e];
+            t23[e] = __fadd_rn(vc, __fmul_rn(-2.f, qt[e]));
+            t4[e] = __fsub_rn(t2s[e], vc);
+        }
+        __syncthreads();
+        const uint8_t* cp = a.codes + off * a.M;
+        const uint8_t* lp = a.lambdas + off;
+        for (int64_t j0 = (int64_t)wave * 64; j0 < len; j0 += 256) {
+            const int64_t j = j0 + lane;
+            const bool valid = j < len;
+            float dist = 0.f;
+            if (valid) {
+                const uint8_t* cj = cp + j * a.M;
+                const float l = a.lambda_info[lp[j]];
+                float s23 = 0.f, s4 = 0.f;
+                const float* p23 = t23;
+                const float* p4 = t4;
+                if ((a.M & 3) == 0) {
+                    const uint32_t* cw = reinterpret_cast<const uint32_t*>(cj);
+                    for (int wd = 0; wd < a.M / 4; wd++) {
+                        const uint32_t cc = cw[wd];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t code = (cc >> (8 * b)) & 255u;
+                            s23 = __fadd_rn(s23, p23[code]);
+                            s4 = __fadd_rn(s4, p4[code]);
+                            p23 += a.ksub;
+                            p4 += a.ksub;
+                        }
+                    }
+                } else {
+                    for (int m = 0; m < a.M; m++) {
+                        s23 = __fadd_rn(s23, p23[cj[m]]);
+                        s4 = __fadd_rn(s4, p4[cj[m]]);
+                        p23 += a.ksub;
+                        p4 += a.ksub;
+                    }
+                }
+                const float head = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)),
+                                             __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+                dist = __fadd_rn(__fadd_rn(head, s23), __fmul_rn(l, s4));
+            }
+            sel.offer(dist, pos0 + (uint32_t)j, valid);
+        }
+        pos0 += (uint32_t)len;
+        nscan += (uint64_t)len;
+    }
+    if (t == 0) cum[a.w1] = pos0;
+
+    ScanArgs em;                 // only the fields merge_and_emit reads
+    em.k = a.k;
+    em.nprobe = a.w1;
+    em.store_pairs = 0;
+    em.ids = a.ids;
+    em.D = a.D;
+    em.I = a.I;
+    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane,
+                        [&](int w, int64_t& lkey, int64_t& loff) { lkey = lq[w]; loff = a.line_off[lq[w]]; });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
+}
+
+template <int KPL>
+static void launch_line_scan_t(const LineScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(line_scan_kernel<KPL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL((line_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, lut_region);
+}
+
+void launch_line_scan(const LineScanArgs& a, hipStream_t s) {
+    if (a.nq <= 0) return;
+    size_t lutb = (size_t)2 * a.M * a.ksub * 4;
+    const size_t merge = (size_t)4 * a.k * 8;
+    if (lutb < merge) lutb = merge;
+    lutb = (lutb + 15) & ~(size_t)15;
+    const size_t smem = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 1) * 4 + 16;
+    if (a.k <= 64) launch_line_scan_t<1>(a, (int)lutb, smem, s);
+    else if (a.k <= 256) launch_line_scan_t<4>(a, (int)lutb, smem, s);
+    else launch_line_scan_t<16>(a, (int)lutb, smem, s);
+}
+
+}  // namespace vlq

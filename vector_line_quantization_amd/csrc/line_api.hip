@@ -1,0 +1,416 @@
+// C ABI of the VLQ index (include/vlq_line.h).  Host orchestration only; the coarse
+// stage, the term2 table and the per-query tables are the IVFPQ library's kernels
+// (an embedded vlq_ivfpq handle), the line-specific stages are line.hip.
+#include "../../include/vlq_line.h"
+#include "handle.h"
+#include "line.h"
+
+struct vlq_line_s {
+    vlq_ivfpq_t base = nullptr;          // coarse centroids, PQ, term2, workspace, stream
+    int nedge = 0, nlambda = 0;
+    int64_t nlines = 0, ntotal = 0, ntotal_added = 0;
+    DevBuf edge_info, edge_dist, lambda_info, codes, lambdas, ids, line_off;
+    bool have_graph = false, have_lambda = false;
+    std::vector<int64_t> h_line_off;
+    std::vector<float> h_lambda;
+    DevBuf ws_near, ws_line, ws_lamf, ws_lamb, ws_res, ws_codes, ws_sel_line, ws_sel_b2, ws_sel_g,
+        ws_x, ws_D, ws_I, ws_keys, ws_cdis, stats;
+};
+
+namespace {
+
+int need(vlq_line_t h, bool graph, bool lambda, bool pq) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (!h->base->have_coarse) return fail(VLQ_ERR_STATE, "coarse centroids not set");
+    if (graph && !h->have_graph) return fail(VLQ_ERR_STATE, "centroid graph not set/built");
+    if (lambda && !h->have_lambda) return fail(VLQ_ERR_STATE, "lambda codebook not set");
+    if (pq && !h->base->have_pq) return fail(VLQ_ERR_STATE, "PQ centroids not set");
+    return VLQ_OK;
+}
+
+// nearest centroid + line + lambda for device-resident x; results in ws_near/ws_line/ws_lamf
+int assign_dev(vlq_line_t h, int64_t n, const float* xd) {
+    vlq_ivfpq_t b = h->base;
+    TRY(h->ws_near.reserve((size_t)n * 8));
+    TRY(h->ws_line.reserve((size_t)n * 4));
+    TRY(h->ws_lamf.reserve((size_t)n * 4));
+    TRY(b->ws_misc.reserve((size_t)n * 4));
+    const int64_t page = query_page(b);
+    for (int64_t i0 = 0; i0 < n; i0 += page) {
+        const int64_t ni = std::min(page, n - i0);
+        // quantizer 1-NN with true distances (classifyAndAddVectors: query(vecs, 1, ..., true))
+        TRY(coarse_page(b, ni, xd + i0 * b->d, 1, b->ws_misc.as<float>() + i0,
+                        h->ws_near.as<int64_t>() + i0, false, false));
+    }
+    vlq::launch_line_assign(xd, n, b->d, b->coarse.as<float>(), h->ws_near.as<int64_t>(),
+                            h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge,
+                            h->ws_line.as<int32_t>(), h->ws_lamf.as<float>(), b->stream);
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
+// full encode on device: ws_line, ws_lamb, ws_codes
+int encode_dev(vlq_line_t h, int64_t n, const float* xd) {
+    vlq_ivfpq_t b = h->base;
+    TRY(assign_dev(h, n, xd));
+    TRY(h->ws_lamb.reserve((size_t)n));
+    TRY(h->ws_res.reserve((size_t)n * b->d * 4));
+    TRY(h->ws_codes.reserve((size_t)n * b->M));
+    vlq::launch_lambda_quantize(h->ws_lamf.as<float>(), n, h->lambda_info.as<float>(), h->nlambda,
+                                h->ws_lamb.as<uint8_t>(), b->stream);
+    vlq::launch_line_residuals(xd, n, b->d, b->coarse.as<float>(), h->edge_info.as<int32_t>(), h->nedge,
+                               h->ws_line.as<int32_t>(), h->ws_lamb.as<uint8_t>(),
+                               h->lambda_info.as<float>(), h->ws_res.as<float>(), b->stream);
+    // PQ code of the residual: first minimum per sub-quantizer (ProductQuantizer.cpp:311-336)
+    vlq::launch_residual_encode(h->ws_res.as<float>(), n, b->d, b->coarse.as<float>(), nullptr, 0,
+                                b->pq.as<float>(), b->M, b->ksub, b->dsub, h->ws_codes.as<uint8_t>(),
+                                b->stream);
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlq_line_create(vlq_line_t* out, int device, int d, int nlist, int M, int nbits, int nedge,
+                    int nlambda) {
+    if (!out) return fail(VLQ_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (nedge < 1 || nedge >= nlist) return fail(VLQ_ERR_INVALID, "nedge=%d must be in 1..nlist-1", nedge);
+    if (nedge + 1 > VLQ_MAX_NPROBE) return fail(VLQ_ERR_UNSUPPORTED, "nedge > 1023");
+    if (nlambda < 1 || nlambda > 256) return fail(VLQ_ERR_INVALID, "nlambda=%d outside 1..256 (one byte)", nlambda);
+    if ((int64_t)nlist * nedge >= (int64_t(1) << 31)) return fail(VLQ_ERR_UNSUPPORTED, "nlist*nedge >= 2^31");
+    vlq_line_s* h = new (std::nothrow) vlq_line_s();
+    if (!h) return fail(VLQ_ERR_INVALID, "out of memory");
+    int rc = vlq_ivfpq_create(&h->base, device, d, nlist, M, nbits);
+    if (rc != VLQ_OK) { delete h; return rc; }
+    h->nedge = nedge; h->nlambda = nlambda; h->nlines = (int64_t)nlist * nedge;
+    h->h_line_off.assign((size_t)h->nlines + 1, 0);
+    rc = h->line_off.reserve(((size_t)h->nlines + 1) * 8);
+    if (rc == VLQ_OK) rc = h->stats.reserve(16);
+    if (rc == VLQ_OK) rc = h->codes.reserve(16);
+    if (rc == VLQ_OK) rc = h->lambdas.reserve(16);
+    if (rc == VLQ_OK) rc = h->ids.reserve(16);
+    if (rc != VLQ_OK) { vlq_line_destroy(h); return rc; }
+    (void)hipMemsetAsync(h->line_off.p, 0, ((size_t)h->nlines + 1) * 8, h->base->stream);
+    (void)hipMemsetAsync(h->stats.p, 0, 16, h->base->stream);
+    (void)hipStreamSynchronize(h->base->stream);
+    *out = h;
+    return VLQ_OK;
+}
+
+void vlq_line_destroy(vlq_line_t h) {
+    if (!h) return;
+    if (h->base) { (void)hipSetDevice(h->base->device); (void)hipStreamSynchronize(h->base->stream); }
+    DevBuf* bufs[] = {&h->edge_info, &h->edge_dist, &h->lambda_info, &h->codes, &h->lambdas, &h->ids,
+                      &h->line_off, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
+                      &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_x, &h->ws_D,
+                      &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats};
+    for (auto b : bufs) b->release();
+    if (h->base) vlq_ivfpq_destroy(h->base);
+    delete h;
+}
+
+int vlq_line_set_stream(vlq_line_t h, void* s) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    return vlq_ivfpq_set_stream(h->base, s);
+}
+
+int vlq_line_set_coarse_centroids(vlq_line_t h, const float* c) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    h->have_graph = false;
+    return vlq_ivfpq_set_coarse_centroids(h->base, c);
+}
+
+int vlq_line_set_pq_centroids(vlq_line_t h, const float* c) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    return vlq_ivfpq_set_pq_centroids(h->base, c);
+}
+
+int vlq_line_set_lambda_codebook(vlq_line_t h, const float* li) {
+    if (!h || !li) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h->base));
+    TRY(h->lambda_info.reserve((size_t)h->nlambda * 4));
+    HIP_TRY(hipMemcpyAsync(h->lambda_info.p, li, (size_t)h->nlambda * 4, hipMemcpyDefault, h->base->stream));
+    h->h_lambda.resize(h->nlambda);
+    HIP_TRY(hipMemcpyAsync(h->h_lambda.data(), h->lambda_info.p, (size_t)h->nlambda * 4, hipMemcpyDeviceToHost, h->base->stream));
+    HIP_TRY(hipStreamSynchronize(h->base->stream));
+    h->have_lambda = true;
+    return VLQ_OK;
+}
+
+int vlq_line_set_graph(vlq_line_t h, const int32_t* ei, const float* ed) {
+    if (!h || !ei || !ed) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h->base));
+    const size_t n = (size_t)h->nlines;
+    std::vector<int32_t> chk(n);
+    HIP_TRY(hipMemcpy(chk.data(), ei, n * 4, hipMemcpyDefault));
+    for (size_t i = 0; i < n; i++)
+        if (chk[i] < 0 || chk[i] >= h->base->nlist) return fail(VLQ_ERR_INVALID, "edge_info[%zu]=%d out of range", i, chk[i]);
+    TRY(h->edge_info.reserve(n * 4));
+    TRY(h->edge_dist.reserve(n * 4));
+    HIP_TRY(hipMemcpyAsync(h->edge_info.p, chk.data(), n * 4, hipMemcpyHostToDevice, h->base->stream));
+    HIP_TRY(hipMemcpyAsync(h->edge_dist.p, ed, n * 4, hipMemcpyDefault, h->base->stream));
+    HIP_TRY(hipStreamSynchronize(h->base->stream));
+    h->have_graph = true;
+    return VLQ_OK;
+}
+
+int vlq_line_build_graph(vlq_line_t h, int32_t* ei_out, float* ed_out) {
+    TRY(need(h, false, false, false));
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    const int nl = b->nlist, E = h->nedge, k = E + 1;
+    // self-query of the centroid set for nedge+1 neighbours (buildGraphNonPaged_, :869-893)
+    std::vector<float> D((size_t)nl * k);
+    std::vector<int64_t> I((size_t)nl * k);
+    TRY(h->ws_cdis.reserve((size_t)nl * k * 4));
+    TRY(h->ws_keys.reserve((size_t)nl * k * 8));
+    const int64_t page = query_page(b);
+    for (int64_t i0 = 0; i0 < nl; i0 += page) {
+        const int64_t ni = std::min<int64_t>(page, nl - i0);
+        TRY(coarse_page(b, ni, b->coarse.as<float>() + i0 * b->d, k, h->ws_cdis.as<float>() + i0 * k,
+                        h->ws_keys.as<int64_t>() + i0 * k, false, false));
+    }
+    HIP_TRY(hipMemcpyAsync(D.data(), h->ws_cdis.p, D.size() * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(I.data(), h->ws_keys.p, I.size() * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    std::vector<int32_t> ei((size_t)nl * E);
+    std::vector<float> ed((size_t)nl * E);
+    for (int i = 0; i < nl; i++)
+        for (int e = 0; e < E; e++) {   // first column (the centroid itself) dropped
+            ei[(size_t)i * E + e] = (int32_t)I[(size_t)i * k + e + 1];
+            ed[(size_t)i * E + e] = D[(size_t)i * k + e + 1];
+        }
+    TRY(vlq_line_set_graph(h, ei.data(), ed.data()));
+    if (ei_out) memcpy(ei_out, ei.data(), ei.size() * 4);
+    if (ed_out) memcpy(ed_out, ed.data(), ed.size() * 4);
+    return VLQ_OK;
+}
+
+int vlq_line_assign(vlq_line_t h, int64_t n, const float* x, int32_t* line_id, float* lambdaf) {
+    TRY(need(h, true, false, false));
+    if (n < 0 || (n > 0 && (!x || !line_id || !lambdaf))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    const void* xd;
+    TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
+    TRY(assign_dev(h, n, (const float*)xd));
+    HIP_TRY(hipMemcpyAsync(line_id, h->ws_line.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(lambdaf, h->ws_lamf.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return VLQ_OK;
+}
+
+int vlq_line_residuals(vlq_line_t h, int64_t n, const float* x, float* residuals) {
+    TRY(need(h, true, true, false));
+    if (n < 0 || (n > 0 && (!x || !residuals))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    const void* xd;
+    TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
+    TRY(assign_dev(h, n, (const float*)xd));
+    TRY(h->ws_lamb.reserve((size_t)n));
+    TRY(h->ws_res.reserve((size_t)n * b->d * 4));
+    vlq::launch_lambda_quantize(h->ws_lamf.as<float>(), n, h->lambda_info.as<float>(), h->nlambda,
+                                h->ws_lamb.as<uint8_t>(), b->stream);
+    vlq::launch_line_residuals((const float*)xd, n, b->d, b->coarse.as<float>(), h->edge_info.as<int32_t>(),
+                               h->nedge, h->ws_line.as<int32_t>(), h->ws_lamb.as<uint8_t>(),
+                               h->lambda_info.as<float>(), h->ws_res.as<float>(), b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(residuals, h->ws_res.p, (size_t)n * b->d * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return VLQ_OK;
+}
+
+int vlq_line_encode(vlq_line_t h, int64_t n, const float* x, int32_t* line_id, uint8_t* lambda,
+                    uint8_t* codes) {
+    TRY(need(h, true, true, true));
+    if (n < 0 || (n > 0 && (!x || !line_id || !lambda || !codes))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    const void* xd;
+    TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
+    TRY(encode_dev(h, n, (const float*)xd));
+    HIP_TRY(hipMemcpyAsync(line_id, h->ws_line.p, (size_t)n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(lambda, h->ws_lamb.p, (size_t)n, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(codes, h->ws_codes.p, (size_t)n * b->M, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return VLQ_OK;
+}
+
+int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambdas, const int64_t* ids,
+                       const int64_t* line_offsets) {
+    if (!h || !line_offsets) return fail(VLQ_ERR_INVALID, "null argument");
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    std::vector<int64_t> off((size_t)h->nlines + 1);
+    HIP_TRY(hipMemcpy(off.data(), line_offsets, off.size() * 8, hipMemcpyDefault));
+    if (off[0] != 0) return fail(VLQ_ERR_INVALID, "line_offsets[0] != 0");
+    for (int64_t i = 0; i < h->nlines; i++)
+        if (off[i + 1] < off[i]) return fail(VLQ_ERR_INVALID, "line_offsets not monotone at %ld", (long)i);
+    const int64_t nt = off[h->nlines];
+    if (nt > 0 && (!codes || !lambdas || !ids)) return fail(VLQ_ERR_INVALID, "null codes/lambdas/ids");
+    TRY(h->codes.reserve((size_t)nt * b->M + 16));
+    TRY(h->lambdas.reserve((size_t)nt + 16));
+    TRY(h->ids.reserve((size_t)nt * 8 + 16));
+    if (nt > 0) {
+        HIP_TRY(hipMemcpyAsync(h->codes.p, codes, (size_t)nt * b->M, hipMemcpyDefault, b->stream));
+        HIP_TRY(hipMemcpyAsync(h->lambdas.p, lambdas, (size_t)nt, hipMemcpyDefault, b->stream));
+        HIP_TRY(hipMemcpyAsync(h->ids.p, ids, (size_t)nt * 8, hipMemcpyDefault, b->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(h->line_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    h->h_line_off.swap(off);
+    h->ntotal = nt;
+    return VLQ_OK;
+}
+
+int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids) {
+    TRY(need(h, true, true, true));
+    if (n < 0 || (n > 0 && !x)) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    std::vector<int32_t> line((size_t)n);
+    std::vector<uint8_t> lam((size_t)n), nc((size_t)n * b->M);
+    TRY(vlq_line_encode(h, n, x, line.data(), lam.data(), nc.data()));
+    std::vector<int64_t> ids_in;
+    if (xids) { ids_in.resize((size_t)n); HIP_TRY(hipMemcpy(ids_in.data(), xids, (size_t)n * 8, hipMemcpyDefault)); }
+    // host-side stable append per line (the reference also keeps the codes on the host
+    // until they are written out, gpu/GpuIndexIVFPQ.cu:852-857)
+    std::vector<uint8_t> oc((size_t)h->ntotal * b->M), ol((size_t)h->ntotal);
+    std::vector<int64_t> oi((size_t)h->ntotal);
+    if (h->ntotal > 0) {
+        HIP_TRY(hipMemcpy(oc.data(), h->codes.p, oc.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ol.data(), h->lambdas.p, ol.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(oi.data(), h->ids.p, oi.size() * 8, hipMemcpyDeviceToHost));
+    }
+    std::vector<int64_t> new_off((size_t)h->nlines + 1, 0);
+    for (int64_t i = 0; i < n; i++) if (line[i] >= 0) new_off[(size_t)line[i] + 1]++;
+    for (int64_t l = 0; l < h->nlines; l++)
+        new_off[l + 1] += new_off[l] + (h->h_line_off[l + 1] - h->h_line_off[l]);
+    const int64_t nt = new_off[h->nlines];
+    std::vector<uint8_t> hc((size_t)nt * b->M), hl((size_t)nt);
+    std::vector<int64_t> hi((size_t)nt), fill((size_t)h->nlines);
+    for (int64_t l = 0; l < h->nlines; l++) {
+        const int64_t o = h->h_line_off[l], len = h->h_line_off[l + 1] - o;
+        if (len > 0) {
+            memcpy(&hc[(size_t)new_off[l] * b->M], &oc[(size_t)o * b->M], (size_t)len * b->M);
+            memcpy(&hl[(size_t)new_off[l]], &ol[(size_t)o], (size_t)len);
+            memcpy(&hi[(size_t)new_off[l]], &oi[(size_t)o], (size_t)len * 8);
+        }
+        fill[l] = new_off[l] + len;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (line[i] < 0) continue;
+        const int64_t p = fill[line[i]]++;
+        memcpy(&hc[(size_t)p * b->M], &nc[(size_t)i * b->M], (size_t)b->M);
+        hl[(size_t)p] = lam[(size_t)i];
+        hi[(size_t)p] = xids ? ids_in[(size_t)i] : h->ntotal_added + i;
+    }
+    TRY(vlq_line_set_lists(h, hc.data(), hl.data(), hi.data(), new_off.data()));
+    h->ntotal_added += n;
+    return VLQ_OK;
+}
+
+int64_t vlq_line_ntotal(vlq_line_t h) { return h ? h->ntotal : -1; }
+
+int vlq_line_list_length(vlq_line_t h, int64_t line, int64_t* len) {
+    if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
+    if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
+    *len = h->h_line_off[line + 1] - h->h_line_off[line];
+    return VLQ_OK;
+}
+
+int vlq_line_get_list(vlq_line_t h, int64_t line, uint8_t* codes_out, uint8_t* lambdas_out, int64_t* ids_out) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    const int64_t o = h->h_line_off[line], len = h->h_line_off[line + 1] - o;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (len > 0 && codes_out) HIP_TRY(hipMemcpy(codes_out, h->codes.as<uint8_t>() + o * b->M, (size_t)len * b->M, hipMemcpyDeviceToHost));
+    if (len > 0 && lambdas_out) HIP_TRY(hipMemcpy(lambdas_out, h->lambdas.as<uint8_t>() + o, (size_t)len, hipMemcpyDeviceToHost));
+    if (len > 0 && ids_out) HIP_TRY(hipMemcpy(ids_out, h->ids.as<int64_t>() + o, (size_t)len * 8, hipMemcpyDeviceToHost));
+    return VLQ_OK;
+}
+
+int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1, int k, float* D,
+                    int64_t* I, int32_t* lines_out) {
+    TRY(need(h, true, true, true));
+    if (n < 0 || (n > 0 && (!x || !D || !I))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (nprobe < 1 || nprobe > VLQ_MAX_NPROBE) return fail(VLQ_ERR_INVALID, "nprobe=%d outside 1..1024", nprobe);
+    if (w1 < 1 || w1 > 1024) return fail(VLQ_ERR_INVALID, "w1=%d outside 1..1024", w1);
+    if (k < 1 || k > VLQ_MAX_K) return fail(VLQ_ERR_INVALID, "k=%d outside 1..1024", k);
+    if (n == 0) return VLQ_OK;
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    TRY(vlq_ivfpq_set_search_options(b, 1, 1, 0));
+    TRY(ensure_term2(b));
+    nprobe = std::min(nprobe, b->nlist);          // IVFPQ.cu:702
+    const size_t E = (size_t)b->M * b->ksub;
+    const void* xd;
+    TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
+    void *Dd, *Id;
+    bool copyD, copyI;
+    TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
+    TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
+    const int64_t page = query_page(b);
+    const int64_t pn = std::min(n, page);
+    TRY(h->ws_keys.reserve((size_t)pn * nprobe * 8));
+    TRY(h->ws_cdis.reserve((size_t)pn * nprobe * 4));
+    TRY(h->ws_sel_line.reserve((size_t)n * w1 * 4));
+    TRY(h->ws_sel_b2.reserve((size_t)pn * w1 * 4));
+    TRY(h->ws_sel_g.reserve((size_t)pn * w1 * 4));
+    TRY(b->ws_qtab.reserve((size_t)pn * E * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += page) {
+        const int64_t ni = std::min(page, n - i0);
+        const float* xi = (const float*)xd + i0 * b->d;
+        // 1. all centroid "distances" without |q|^2 + the nprobe nearest (Distance.cu:233-383)
+        TRY(coarse_page(b, ni, xi, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false));
+        // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
+        int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
+        vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
+                                h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
+                                sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream);
+        // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
+        vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
+                              b->ws_qtab.as<float>(), b->stream);
+        // 4. scan + top-k
+        vlq::LineScanArgs a;
+        a.codes = h->codes.as<uint8_t>(); a.lambdas = h->lambdas.as<uint8_t>(); a.ids = h->ids.as<int64_t>();
+        a.line_off = h->line_off.as<int64_t>(); a.term2 = b->term2.as<float>(); a.qtab = b->ws_qtab.as<float>();
+        a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
+        a.lambda_info = h->lambda_info.as<float>();
+        a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();
+        a.D = (float*)Dd + i0 * k; a.I = (int64_t*)Id + i0 * k;
+        a.ncode = h->stats.as<unsigned long long>();
+        a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;
+        a.max_line_codes = VLQ_LINE_MAX_CODES;
+        vlq::launch_line_scan(a, b->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    if (lines_out) HIP_TRY(hipMemcpyAsync(lines_out, h->ws_sel_line.p, (size_t)n * w1 * 4, hipMemcpyDeviceToHost, b->stream));
+    TRY(finish_outputs(b, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
+    if (lines_out) HIP_TRY(hipStreamSynchronize(b->stream));
+    return VLQ_OK;
+}
+
+int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    vlq_ivfpq_t b = h->base;
+    TRY(set_dev(b));
+    unsigned long long st[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 16, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (ncode) *ncode = st[0];
+    if (reset) HIP_TRY(hipMemsetAsync(h->stats.p, 0, 16, b->stream));
+    return VLQ_OK;
+}
+
+}  // extern "C"

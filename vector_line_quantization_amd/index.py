@@ -174,3 +174,125 @@ class GpuIVFPQ:
         calls = C.c_int64()
         check(lib().vlq_ivfpq_profile_read(self._h, ms, C.byref(calls), C.c_int(int(reset))))
         return {"coarse_ms": ms[0], "tables_ms": ms[1], "scan_ms": ms[2], "scan_calls": calls.value}
+
+
+class GpuVLQ:
+    """The fork's vector-and-line-quantization index (include/vlq_line.h):
+    GpuIndexIVFPQ(resources, dims, nlist, M, nbits, nedge, nLambda, ...) of
+    gpu/GpuIndexIVFPQ.h:60-68 -- construct, load trained state, add, search."""
+
+    def __init__(self, d, nlist, M, nbits, nedge, nlambda, device=0):
+        self.d, self.nlist, self.M, self.nbits = d, nlist, M, nbits
+        self.nedge, self.nlambda, self.ksub = nedge, nlambda, 1 << nbits
+        self._h = C.c_void_p()
+        check(lib().vlq_line_create(C.byref(self._h), C.c_int(device), C.c_int(d), C.c_int(nlist),
+                                    C.c_int(M), C.c_int(nbits), C.c_int(nedge), C.c_int(nlambda)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().vlq_line_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(lib().vlq_line_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def set_coarse_centroids(self, c):
+        p, _k = _ptr(c, np.float32)
+        check(lib().vlq_line_set_coarse_centroids(self._h, p))
+
+    def set_pq_centroids(self, c):
+        p, _k = _ptr(c, np.float32)
+        check(lib().vlq_line_set_pq_centroids(self._h, p))
+
+    def set_lambda_codebook(self, li):
+        p, _k = _ptr(li, np.float32)
+        check(lib().vlq_line_set_lambda_codebook(self._h, p))
+
+    def set_graph(self, edge_info, edge_dist):
+        pe, _a = _ptr(edge_info, np.int32)
+        pd, _b = _ptr(edge_dist, np.float32)
+        check(lib().vlq_line_set_graph(self._h, pe, pd))
+
+    def build_graph(self):
+        ei = np.empty((self.nlist, self.nedge), np.int32)
+        ed = np.empty((self.nlist, self.nedge), np.float32)
+        check(lib().vlq_line_build_graph(self._h, ei.ctypes.data_as(C.c_void_p), ed.ctypes.data_as(C.c_void_p)))
+        return ei, ed
+
+    def assign(self, x):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        line = np.empty((n,), np.int32)
+        lam = np.empty((n,), np.float32)
+        check(lib().vlq_line_assign(self._h, C.c_int64(n), px, line.ctypes.data_as(C.c_void_p),
+                                    lam.ctypes.data_as(C.c_void_p)))
+        return line, lam
+
+    def residuals(self, x):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        out = np.empty((n, self.d), np.float32)
+        check(lib().vlq_line_residuals(self._h, C.c_int64(n), px, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def encode(self, x):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        line = np.empty((n,), np.int32)
+        lam = np.empty((n,), np.uint8)
+        codes = np.empty((n, self.M), np.uint8)
+        check(lib().vlq_line_encode(self._h, C.c_int64(n), px, line.ctypes.data_as(C.c_void_p),
+                                    lam.ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p)))
+        return line, lam, codes
+
+    def add(self, x, xids=None):
+        px, _a = _ptr(x, np.float32)
+        pi, _b = _ptr(xids, np.int64)
+        check(lib().vlq_line_add(self._h, C.c_int64(x.shape[0]), px, pi))
+
+    def set_lists(self, codes, lambdas, ids, line_offsets):
+        pc, _a = _ptr(codes, np.uint8)
+        pl, _b = _ptr(lambdas, np.uint8)
+        pi, _c = _ptr(ids, np.int64)
+        po, _d = _ptr(line_offsets, np.int64)
+        check(lib().vlq_line_set_lists(self._h, pc, pl, pi, po))
+
+    @property
+    def ntotal(self):
+        return int(lib().vlq_line_ntotal(self._h))
+
+    def get_list(self, line):
+        n = C.c_int64()
+        check(lib().vlq_line_list_length(self._h, C.c_int64(line), C.byref(n)))
+        codes = np.empty((n.value, self.M), np.uint8)
+        lam = np.empty((n.value,), np.uint8)
+        ids = np.empty((n.value,), np.int64)
+        check(lib().vlq_line_get_list(self._h, C.c_int64(line), codes.ctypes.data_as(C.c_void_p),
+                                      lam.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p)))
+        return codes, lam, ids
+
+    def search(self, x, nprobe, w1, k, D=None, I=None, return_lines=False):
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        if D is None:
+            D = GpuIVFPQ._out(self, None, (n, k), np.float32, x)
+        if I is None:
+            I = GpuIVFPQ._out(self, None, (n, k), np.int64, x)
+        pD, _b = _ptr(D)
+        pI, _c = _ptr(I)
+        lines = np.empty((n, w1), np.int32) if return_lines else None
+        pl = lines.ctypes.data_as(C.c_void_p) if return_lines else None
+        check(lib().vlq_line_search(self._h, C.c_int64(n), px, C.c_int(nprobe), C.c_int(w1), C.c_int(k),
+                                    pD, pI, pl))
+        return (D, I, lines) if return_lines else (D, I)
+
+    def stats(self, reset=False):
+        nc = C.c_uint64()
+        check(lib().vlq_line_stats(self._h, C.byref(nc), C.c_int(int(reset))))
+        return nc.value
