@@ -1,8 +1,9 @@
 // HIP kernels of the VLQ (vector and line quantization) path for gfx950.
 //
-// Stage map (reference CUDA kernel -> kernel here), arithmetic as fixed by
-// oracle/vlq_oracle.cpp (the reference leaves operation order / ties to nvcc and to
-// unstable sorts; see that file's header):
+// Stage map (reference CUDA kernel -> kernel here).  The reference leaves the operation
+// order to nvcc's contraction and ties to unstable sorts; here every fp32 operation is an
+// explicit unfused multiply/add/divide in the order written, ties go to the lowest index
+// (VLQ section):
 //   get1BinKernel_nms        gpu/GpuIndexFlat.cu:433-557         -> line_assign_kernel
 //   assignLambdaKernel       gpu/GpuIndexFlat.cu:559-602         -> lambda_quantize_kernel
 //   calResidual              gpu/GpuIndexFlat.cu:1092-1129        -> line_residual_kernel
