@@ -1,11 +1,12 @@
 // faiss::gpu::GpuIndexIVFPQ construction and search surface
 // (gpu/GpuIndexIVFPQ.h:24-234, gpu/GpuIndexIVF.h:25-95, gpu/GpuIndex.h:19-102,
-// gpu/GpuIndexFlat.h:27-49) over the MI355X library.  The fork's VLQ members
-// (nedge / nLambda constructor, graph files) belong to the VLQ row of SURVEY.md §8f.
+// gpu/GpuIndexFlat.h:27-49) over the MI355X library, including the fork's VLQ
+// constructor (nedge, nLambda) with its train / add / search path (vlq_line.h).
 #pragma once
 #include <vector>
 
 #include "compat.h"
+#include "../../vlq_line.h"
 #include "GpuIndicesOptions.h"
 #include "GpuResources.h"
 
@@ -73,7 +74,35 @@ class GpuIndexIVFPQ : public GpuIndex {
     is_trained = false;
     create_();
   }
-  ~GpuIndexIVFPQ() override { if (h_) vlq_ivfpq_destroy(h_); }
+  /// the fork's VLQ index (gpu/GpuIndexIVFPQ.h:60-68): lines between each coarse centroid
+  /// and its `nedge` nearest centroids, `nLambda` scalar positions along a line
+  GpuIndexIVFPQ(GpuResources* resources, int dims, int nlist, int subQuantizers, int bitsPerCode, int nedge,
+                int nLambda, faiss::MetricType metric, GpuIndexIVFPQConfig config = GpuIndexIVFPQConfig())
+      : GpuIndex(resources, dims, metric, config), nLambda_(nLambda), numedge_(nedge), begin_(0), end_(0),
+        w1_(1), ivfpqConfig_(config), nlist_(nlist), nprobe_(1), subQuantizers_(subQuantizers),
+        bitsPerCode_(bitsPerCode), reserveMemoryVecs_(0) {
+    verifyConfig_();
+    FAISS_THROW_IF_NOT_MSG(bitsPerCode_ >= 1 && bitsPerCode_ <= 8, "Bits per code must be <= 8");
+    FAISS_THROW_IF_NOT_MSG(dims % subQuantizers_ == 0, "Number of sub-quantizers must be an even divisor of the dimensions");
+    is_trained = false;
+    VLQ_CHECK(vlq_line_create(&line_, device_, d, nlist_, subQuantizers_, bitsPerCode_, numedge_, nLambda_));
+    VLQ_CHECK(vlq_line_set_stream(line_, (void*)resources_->getDefaultStream(device_)));
+    edgeInfoV_.resize((size_t)nlist_ * numedge_);
+    edgeDistInfoV_.resize((size_t)nlist_ * numedge_);
+    lambdaInfoV_.resize(nLambda_);
+    edgeInfo_ = edgeInfoV_.data(); edgeDistInfo_ = edgeDistInfoV_.data(); lambdaInfo_ = lambdaInfoV_.data();
+  }
+  ~GpuIndexIVFPQ() override { if (h_) vlq_ivfpq_destroy(h_); if (line_) vlq_line_destroy(line_); }
+
+  // public VLQ state of the reference class (gpu/GpuIndexIVFPQ.h:70-81)
+  int nLambda_ = 0;
+  int numedge_ = 0;
+  int begin_ = 0, end_ = 0;   ///< MPI list range of the fork's drivers; unused (query sharding instead)
+  int w1_ = 1;                ///< lines kept per query
+  int* edgeInfo_ = nullptr;
+  float* edgeDistInfo_ = nullptr;
+  float* lambdaInfo_ = nullptr;
+  bool isVLQ() const { return line_ != nullptr; }
   GpuIndexIVFPQ(const GpuIndexIVFPQ&) = delete;
   GpuIndexIVFPQ& operator=(const GpuIndexIVFPQ&) = delete;
 
@@ -164,6 +193,7 @@ class GpuIndexIVFPQ : public GpuIndex {
   /// (GpuIndexIVFPQ::train gpu/GpuIndexIVFPQ.cu:1160-1178 minus the fork's graph build)
   void train(Index::idx_t n, const float* x) override {
     if (is_trained) return;
+    if (line_) { trainVLQ_(n, x); return; }
     faiss::IndexFlatL2 flat(d);
     faiss::IndexIVFPQ cpu(&flat, d, nlist_, subQuantizers_, bitsPerCode_);
 #ifndef VLQ_WITH_REFERENCE_FAISS
@@ -178,12 +208,17 @@ class GpuIndexIVFPQ : public GpuIndex {
   void add(Index::idx_t n, const float* x) override { add_with_ids(n, x, nullptr); }
   void add_with_ids(Index::idx_t n, const float* x, const Index::idx_t* ids) override {
     FAISS_THROW_IF_NOT_MSG(is_trained, "Index not trained");
-    VLQ_CHECK(vlq_ivfpq_add(h_, n, x, (const int64_t*)ids));
+    if (line_) VLQ_CHECK(vlq_line_add(line_, n, x, (const int64_t*)ids));
+    else VLQ_CHECK(vlq_ivfpq_add(h_, n, x, (const int64_t*)ids));
     ntotal += n;
   }
   void search(Index::idx_t n, const float* x, Index::idx_t k, float* distances, Index::idx_t* labels) const override {
     FAISS_THROW_IF_NOT_MSG(is_trained, "Index not trained");
     FAISS_THROW_IF_NOT_MSG(k >= 1 && k <= VLQ_MAX_K, "k outside 1..1024 (gpu/impl/IVFPQ.cu:966-967)");
+    if (line_) {   // searchImpl_ -> IVFPQ::queryGraph (gpu/GpuIndexIVFPQ.cu:1400-1460)
+      VLQ_CHECK(vlq_line_search(line_, n, x, nprobe_, w1_, (int)k, distances, (int64_t*)labels, nullptr));
+      return;
+    }
     if (ivfpqConfig_.indicesOptions == INDICES_IVF) {
       std::vector<int64_t> keys((size_t)n * nprobe_);
       std::vector<float> cd((size_t)n * nprobe_);
@@ -213,6 +248,48 @@ class GpuIndexIVFPQ : public GpuIndex {
   vlq_ivfpq_t handle() const { return h_; }
 
  private:
+  /// GpuIndexIVFPQ::train of the fork (gpu/GpuIndexIVFPQ.cu:1160-1178): coarse k-means,
+  /// centroid graph, then trainResidualQuantizer_ (:346-403): lines + lambdas of a
+  /// training subset, 1-D k-means of the lambdas, PQ on the residuals to the anchors
+  void trainVLQ_(Index::idx_t n, const float* x) {
+    {
+      faiss::IndexFlatL2 flat(d);
+#ifndef VLQ_WITH_REFERENCE_FAISS
+      flat.device = device_;
+#endif
+      ClusteringParameters cp;
+      cp.niter = 10;
+      Clustering clus(d, nlist_, cp);
+      clus.verbose = verbose;
+      clus.train(n, x, flat);
+      coarse_ = clus.centroids;
+    }
+    VLQ_CHECK(vlq_line_set_coarse_centroids(line_, coarse_.data()));
+    VLQ_CHECK(vlq_line_build_graph(line_, edgeInfo_, edgeDistInfo_));
+    const Index::idx_t nt = std::min<Index::idx_t>(n, (Index::idx_t)(1 << bitsPerCode_) * 128);
+    std::vector<int32_t> line(nt);
+    std::vector<float> lambdaf(nt);
+    VLQ_CHECK(vlq_line_assign(line_, nt, x, line.data(), lambdaf.data()));
+    {
+      ClusteringParameters cp;
+      Clustering clus(1, nLambda_, cp);
+      faiss::IndexFlatL2 flat1(1);
+#ifndef VLQ_WITH_REFERENCE_FAISS
+      flat1.device = device_;
+#endif
+      clus.train(nt, lambdaf.data(), flat1);
+      memcpy(lambdaInfo_, clus.centroids.data(), sizeof(float) * nLambda_);
+    }
+    VLQ_CHECK(vlq_line_set_lambda_codebook(line_, lambdaInfo_));
+    std::vector<float> residuals((size_t)nt * d);
+    VLQ_CHECK(vlq_line_residuals(line_, nt, x, residuals.data()));
+    faiss::ProductQuantizer pq(d, subQuantizers_, bitsPerCode_);
+    pq.verbose = verbose;
+    pq.train((int)nt, residuals.data());
+    pqCentroids_ = pq.centroids;
+    VLQ_CHECK(vlq_line_set_pq_centroids(line_, pqCentroids_.data()));
+    is_trained = true;
+  }
   void verifyConfig_() const {
     FAISS_THROW_IF_NOT_MSG(!ivfpqConfig_.useFloat16LookupTables && !ivfpqConfig_.flatConfig.useFloat16,
                            "float16 tables/storage are not built: the path is fp32 for bit parity with the CPU index");
@@ -228,7 +305,10 @@ class GpuIndexIVFPQ : public GpuIndex {
   size_t reserveMemoryVecs_;
   bool usePrecomputed_ = false;
   std::vector<float> coarse_, pqCentroids_;
+  std::vector<int> edgeInfoV_;
+  std::vector<float> edgeDistInfoV_, lambdaInfoV_;
   vlq_ivfpq_t h_ = nullptr;
+  vlq_line_t line_ = nullptr;
 };
 
 } }
