@@ -11,6 +11,8 @@
 //   * workgroups are dealt to XCDs so that queries adjacent in `qorder` (sorted by
 //     nearest coarse centroid) share an L2: their term2 rows and list codes are then
 //     mostly L2 hits instead of fabric reads.  Placement only affects speed.
+#include <type_traits>
+
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
@@ -32,6 +34,10 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
                                                ProbeMeta::bytes(a.nprobe));
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // adc16_fixed() addresses the LUT buffers at LDS offsets 0 / 16384
+    if (__builtin_amdgcn_groupstaticsize() != 0) { *a.bad_key = 2; return; }
+    uint32_t two = 2;
+    asm volatile("" : "+v"(two));   // keep the shift amount in a VGPR (SDWA takes no literal)
     // XCD-aware placement: hardware deals consecutive workgroups round-robin over the 8
     // XCDs, so give XCD x the x-th contiguous chunk of the (sorted) query order.
     int64_t q;
@@ -87,16 +93,21 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         uint4 cc = c0;
         const int nxt = prefetch(ik + 1);
         __syncthreads();
-        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
-            const uint32_t j = j0 + lane;
-            const uint32_t jn = j + NT;
-            uint4 cn = make_uint4(0, 0, 0, 0);
-            if (jn < len) cn = cp[jn];
-            const bool valid = j < len;
-            const float dis = adc16(L, cc, dis0);
-            sel.offer(dis, pos0 + j, valid);
-            cc = cn;
-        }
+        // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
+        auto scan_list = [&](auto bufc) {
+            constexpr int B = decltype(bufc)::value;
+            for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
+                const uint32_t j = j0 + lane;
+                const uint32_t jn = j + NT;
+                uint4 cn = make_uint4(0, 0, 0, 0);
+                if (jn < len) cn = cp[jn];
+                const float dis = adc16_fixed<B>(cc, dis0, two);
+                sel.offer(dis, pos0 + j, j < len);
+                cc = cn;
+            }
+        };
+        if (NBUF == 1 || buf == 0) scan_list(std::integral_constant<int, 0>{});
+        else scan_list(std::integral_constant<int, 1>{});
         nscan += len;
         if (NBUF == 2) buf ^= 1;
         ik = nxt;

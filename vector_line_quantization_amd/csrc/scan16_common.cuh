@@ -72,6 +72,63 @@ __device__ __forceinline__ float adc16(const float* L, const uint4 cc, float dis
     return dis;
 }
 
+// Hand-scheduled form of the 16 LUT gathers of one code for a LUT at a FIXED LDS byte
+// offset (0 or 16384: the two buffers at the start of the kernel's dynamic LDS, which
+// starts at LDS address 0 because the kernel declares no static LDS -- checked at kernel
+// entry).  hipcc spends two VALU ops per lookup (v_bfe_u32 + v_lshl_add_u32); SDWA does the
+// byte extract and the x4 in one, and m*1024 + buffer offset ride in the ds_read offset
+// field.  All 16 reads are issued back to back, one wait, then the caller adds left to
+// right -- the same values and the same addition order as adc16().
+#define VLQ_G16_ASM(O)                                                                              \
+    asm volatile(                                                                                   \
+        "v_lshlrev_b32_sdwa %0, %20, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"  \
+        "v_lshlrev_b32_sdwa %1, %20, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"  \
+        "v_lshlrev_b32_sdwa %2, %20, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"  \
+        "v_lshlrev_b32_sdwa %3, %20, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  \
+        "v_lshlrev_b32_sdwa %4, %20, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"  \
+        "v_lshlrev_b32_sdwa %5, %20, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"  \
+        "v_lshlrev_b32_sdwa %6, %20, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"  \
+        "v_lshlrev_b32_sdwa %7, %20, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  \
+        "v_lshlrev_b32_sdwa %8, %20, %18 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"  \
+        "v_lshlrev_b32_sdwa %9, %20, %18 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"  \
+        "v_lshlrev_b32_sdwa %10, %20, %18 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %11, %20, %18 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %12, %20, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %13, %20, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %14, %20, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %15, %20, %19 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:" #O "+0\n\t"                                                      \
+        "ds_read_b32 %1, %1 offset:" #O "+1024\n\t"                                                   \
+        "ds_read_b32 %2, %2 offset:" #O "+2048\n\t"                                                   \
+        "ds_read_b32 %3, %3 offset:" #O "+3072\n\t"                                                   \
+        "ds_read_b32 %4, %4 offset:" #O "+4096\n\t"                                                   \
+        "ds_read_b32 %5, %5 offset:" #O "+5120\n\t"                                                   \
+        "ds_read_b32 %6, %6 offset:" #O "+6144\n\t"                                                   \
+        "ds_read_b32 %7, %7 offset:" #O "+7168\n\t"                                                   \
+        "ds_read_b32 %8, %8 offset:" #O "+8192\n\t"                                                   \
+        "ds_read_b32 %9, %9 offset:" #O "+9216\n\t"                                                   \
+        "ds_read_b32 %10, %10 offset:" #O "+10240\n\t"                                                \
+        "ds_read_b32 %11, %11 offset:" #O "+11264\n\t"                                                \
+        "ds_read_b32 %12, %12 offset:" #O "+12288\n\t"                                                \
+        "ds_read_b32 %13, %13 offset:" #O "+13312\n\t"                                                \
+        "ds_read_b32 %14, %14 offset:" #O "+14336\n\t"                                                \
+        "ds_read_b32 %15, %15 offset:" #O "+15360\n\t"                                                \
+        "s_waitcnt lgkmcnt(0)"                                                                      \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]),  \
+          "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]),            \
+          "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])                                                   \
+        : "v"(cc.x), "v"(cc.y), "v"(cc.z), "v"(cc.w), "v"(two)                                       \
+        : "memory")
+
+template <int BUF>
+__device__ __forceinline__ float adc16_fixed(const uint4 cc, float dis, uint32_t two) {
+    float v[16];
+    if (BUF == 0) { VLQ_G16_ASM(0); } else { VLQ_G16_ASM(16384); }
+#pragma unroll
+    for (int m = 0; m < 16; m++) dis = __fadd_rn(dis, v[m]);
+    return dis;
+}
+
 // sim_table = term2[key] + (-2) * sim_table_2  (fvec_madd, IndexIVFPQ.cpp:641-644):
 // 4*NI entries per thread, NI 16-byte LDS stores
 template <int NI>
