@@ -96,11 +96,12 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;
+#pragma unroll 2
             for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
                 const uint32_t j = j0 + lane;
-                const uint32_t jn = j + NT;
-                uint4 cn = make_uint4(0, 0, 0, 0);
-                if (jn < len) cn = cp[jn];
+                // next chunk, clamped instead of predicated: a branch-free load (lanes past the
+                // end re-read the last code and are masked out of the selection)
+                const uint4 cn = cp[min(j + NT, len - 1)];
                 const float dis = adc16_fixed<B>(cc, dis0, two);
                 sel.offer(dis, pos0 + j, j < len);
                 cc = cn;
