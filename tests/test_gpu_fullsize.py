@@ -1,0 +1,92 @@
+"""GPU, BASELINE config-1 sizes (1M codes, nlist=4096, M=16x8bit, nprobe=32, k=10,
+10 000 queries): size-independent properties of the hot path plus an oracle check on
+a sample.  Index content is synthetic (random centroids / codes): the properties hold
+for any content."""
+import numpy as np
+import pytest
+
+import vector_line_quantization_amd as vlq
+from oracle import pyoracle
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+D_, NLIST, M, NB, NQ, NPROBE, K = 128, 4096, 16, 1000000, 10000, 32, 10
+
+
+@pytest.fixture(scope="module")
+def world():
+    rng = np.random.default_rng(7)
+    coarse = rng.random((NLIST, D_), dtype=np.float32) * 255
+    pq = (rng.random((M, 256, D_ // M), dtype=np.float32) - 0.5) * 40
+    lens = rng.multinomial(NB, rng.dirichlet(np.full(NLIST, 0.7)))      # imbalanced lists
+    off = np.zeros(NLIST + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    codes = rng.integers(0, 256, (NB, M), dtype=np.uint8)
+    codes[1000:1400] = codes[1000]                                       # exact ties inside a list
+    ids = rng.permutation(NB).astype(np.int64) * 3 + 1
+    # queries near centroids so that probes concentrate like real data
+    xq = (coarse[rng.integers(0, NLIST, NQ)] + rng.standard_normal((NQ, D_)) * 30).astype(np.float32)
+    g = vlq.GpuIVFPQ(D_, NLIST, M, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    g.set_lists(codes, ids, off)
+    ox = pyoracle.OracleIndex(D_, NLIST, M, 8, coarse, pq, codes=codes, ids=ids, list_offsets=off)
+    Dg, Ig = g.search(xq, NPROBE, K)
+    return dict(g=g, ox=ox, xq=xq, D=Dg, I=Ig, off=off, ids=ids)
+
+
+def test_sample_matches_oracle_bit_exact(world):
+    sel = np.arange(0, NQ, 41)[:200]
+    Do, Io = world["ox"].search(world["xq"][sel], NPROBE, K, canonical=True)
+    assert np.array_equal(bits(world["D"][sel]), bits(Do))
+    assert np.array_equal(world["I"][sel], Io)
+
+
+def test_ncode_counter_matches_list_lengths(world):
+    g = world["g"]
+    g.stats(reset=True)
+    cd, keys = g.coarse_search(world["xq"], NPROBE)
+    g.search_preassigned(world["xq"], keys, cd, K)
+    nq, ncode = g.stats(reset=True)
+    lens = np.diff(world["off"])
+    assert ncode == int(lens[keys].sum()) and nq == NQ
+
+
+def test_results_do_not_depend_on_batch_composition(world):
+    """Query order / batch split / paging change which queries share a workgroup
+    neighbourhood and the sort order of the batch -- never a result."""
+    g, xq = world["g"], world["xq"]
+    perm = np.random.default_rng(1).permutation(NQ)
+    Dp, Ip = g.search(xq[perm], NPROBE, K)
+    assert np.array_equal(bits(Dp), bits(world["D"][perm])) and np.array_equal(Ip, world["I"][perm])
+    for lo, hi in ((0, 1), (5, 24), (100, 1100), (1100, 4000)):          # 1 / <20 (direct coarse: see below) / <1024 / >=1024
+        Ds, Is = g.search(xq[lo:hi], NPROBE, K)
+        if hi - lo >= 20:
+            assert np.array_equal(bits(Ds), bits(world["D"][lo:hi])) and np.array_equal(Is, world["I"][lo:hi])
+        else:   # the reference's small-batch coarse path rounds differently (utils.cpp:935-946): labels agree
+            assert (Is == world["I"][lo:hi]).mean() > 0.95
+
+
+def test_smaller_k_is_a_prefix(world):
+    g, xq = world["g"], world["xq"]
+    D5, I5 = g.search(xq[:3000], NPROBE, 5)
+    assert np.array_equal(bits(D5), bits(world["D"][:3000, :5])) and np.array_equal(I5, world["I"][:3000, :5])
+    D1, I1 = g.search(xq[:3000], NPROBE, 1)
+    assert np.array_equal(I1[:, 0], world["I"][:3000, 0])
+
+
+def test_store_pairs_decode_to_the_same_ids(world):
+    g, xq = world["g"], world["xq"][:2000]
+    cd, keys = g.coarse_search(xq, NPROBE)
+    D, I = g.search_preassigned(xq, keys, cd, K)
+    Dp, Ip = g.search_preassigned(xq, keys, cd, K, store_pairs=True)
+    assert np.array_equal(bits(D), bits(Dp))
+    lst, o = Ip >> 32, Ip & 0xFFFFFFFF
+    assert np.array_equal(world["ids"][world["off"][lst] + o], I)
+
+
+def test_more_probes_never_hurt(world):
+    g, xq = world["g"], world["xq"][:2000]
+    D64, _ = g.search(xq, 64, K)
+    assert (D64 <= world["D"][:2000]).all()
