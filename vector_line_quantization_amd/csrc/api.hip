@@ -3,8 +3,6 @@
 // No CPU compute path exists here: every search/add entry point launches kernels.
 #include "handle.h"
 
-#include <cstdlib>
-
 namespace vlq_detail {
 
 int set_dev(vlq_ivfpq_t h) {
@@ -233,8 +231,7 @@ int search_pipelined(vlq_ivfpq_t h, int64_t n, const float* xd, int nprobe, int 
                      int64_t* Id) {
     TRY(ensure_lanes(h));
     TRY(ensure_term2(h));
-    static const int exp_chunks = getenv("VLQ_EXP_CHUNKS") ? atoi(getenv("VLQ_EXP_CHUNKS")) : 0;
-    const int nchunk = exp_chunks > 0 ? exp_chunks : (int)std::min<int64_t>(8, std::max<int64_t>(2, n / 2048));
+    const int nchunk = (int)std::min<int64_t>(8, std::max<int64_t>(2, n / 2048));
     const int64_t chunk = std::min((n + nchunk - 1) / nchunk, query_page(h));
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (auto& L : h->lanes) HIP_TRY(hipStreamWaitEvent(L.s, h->ev_fork, 0));
