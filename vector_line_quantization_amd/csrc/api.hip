@@ -201,62 +201,6 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
     return VLQ_OK;
 }
 
-void swap_lane(vlq_ivfpq_t h, vlq_ivfpq_s::Lane& L) {
-    std::swap(h->stream, L.s);
-    std::swap(h->ws_qn, L.ws_qn);
-    std::swap(h->ws_dist, L.ws_dist);
-    std::swap(h->ws_qtab, L.ws_qtab);
-    std::swap(h->ws_hist, L.ws_hist);
-    std::swap(h->ws_qorder, L.ws_qorder);
-}
-
-int ensure_lanes(vlq_ivfpq_t h) {
-    if (h->lanes_ready) return VLQ_OK;
-    for (auto& L : h->lanes) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (auto& e : h->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& e : h->ev_coarse) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->lanes_ready = true;
-    return VLQ_OK;
-}
-
-// Large batches: cut into chunks and run them on two lanes, staggered by one coarse stage:
-//   lane A: coarse(0) scan(0)            coarse(2) scan(2)
-//   lane B:           coarse(1) scan(1)            coarse(3) scan(3)
-// coarse(i+1) starts when coarse(i) is done, so the f32-MFMA GEMM of one chunk shares the
-// CUs with the LDS/VALU-bound list scan of the previous one (2 scan workgroups + 1 GEMM
-// workgroup fit one CU's LDS and registers).  Chunks are independent queries: results are
-// the same as for the unsplit batch.
-int search_pipelined(vlq_ivfpq_t h, int64_t n, const float* xd, int nprobe, int k, float* Dd,
-                     int64_t* Id) {
-    TRY(ensure_lanes(h));
-    TRY(ensure_term2(h));
-    const int nchunk = (int)std::min<int64_t>(8, std::max<int64_t>(2, n / 2048));
-    const int64_t chunk = std::min((n + nchunk - 1) / nchunk, query_page(h));
-    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    for (auto& L : h->lanes) HIP_TRY(hipStreamWaitEvent(L.s, h->ev_fork, 0));
-    int c = 0, rc = VLQ_OK;
-    for (int64_t i0 = 0; i0 < n && rc == VLQ_OK; i0 += chunk, c++) {
-        const int64_t ni = std::min(chunk, n - i0);
-        auto& L = h->lanes[c & 1];
-        if (c > 0) HIP_TRY(hipStreamWaitEvent(L.s, h->ev_coarse[(c - 1) & 7], 0));
-        swap_lane(h, L);
-        rc = coarse_dev(h, ni, xd + i0 * h->d, nprobe, h->ws_cdis.as<float>() + i0 * nprobe,
-                        h->ws_keys.as<int64_t>() + i0 * nprobe);
-        if (rc == VLQ_OK && hipEventRecord(h->ev_coarse[c & 7], h->stream) != hipSuccess)
-            rc = fail(VLQ_ERR_HIP, "hipEventRecord failed");
-        if (rc == VLQ_OK)
-            rc = scan_dev(h, ni, xd + i0 * h->d, h->ws_keys.as<int64_t>() + i0 * nprobe,
-                          h->ws_cdis.as<float>() + i0 * nprobe, nprobe, k, Dd + i0 * k, Id + i0 * k, 0);
-        swap_lane(h, L);
-    }
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventRecord(h->ev_join[i], h->lanes[i].s));
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
-    }
-    return rc;
-}
-
 int check_search_args(vlq_ivfpq_t h, int64_t n, const void* x, int nprobe, int k, const void* D,
                       const void* I) {
     if (n < 0) return fail(VLQ_ERR_INVALID, "n < 0");
@@ -340,14 +284,6 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats};
     for (auto b : bufs) b->release();
-    for (auto& L : h->lanes) {
-        DevBuf* lb[] = {&L.ws_qn, &L.ws_dist, &L.ws_qtab, &L.ws_hist, &L.ws_qorder};
-        for (auto b : lb) b->release();
-        if (L.s) { (void)hipStreamSynchronize(L.s); (void)hipStreamDestroy(L.s); }
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (auto e : h->ev_join) if (e) (void)hipEventDestroy(e);
-    for (auto e : h->ev_coarse) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -512,13 +448,9 @@ int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k
     TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
     TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
     // IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081): quantizer->search, then search_knn_with_key
-    if (n >= 4096) {
-        TRY(search_pipelined(h, n, (const float*)xd, nprobe, k, (float*)Dd, (int64_t*)Id));
-    } else {
-        TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
-        TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
-                     (float*)Dd, (int64_t*)Id, 0));
-    }
+    TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
+    TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
+                 (float*)Dd, (int64_t*)Id, 0));
     return finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8);
 }
 

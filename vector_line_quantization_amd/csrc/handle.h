@@ -91,16 +91,6 @@ struct vlq_ivfpq_s {
     DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
     uint64_t stat_nq = 0;
 
-    // two auxiliary lanes (stream + private workspace) for the chunk-pipelined search:
-    // the MFMA-bound coarse stage of chunk i+1 runs beside the LDS-bound scan of chunk i
-    struct Lane {
-        hipStream_t s = nullptr;
-        DevBuf ws_qn, ws_dist, ws_qtab, ws_hist, ws_qorder;
-    };
-    Lane lanes[2];
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_coarse[8] = {};
-    bool lanes_ready = false;
-
     // profiling
     bool prof = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
