@@ -54,6 +54,10 @@ struct orc_index {
     const uint8_t* codes;           // [ntotal][code_size], list-major
     const int64_t* ids;             // [ntotal], list-major
     const int64_t* list_offsets;    // [nlist+1]
+    // inverted multi-index coarse quantizer (MultiIndexQuantizer, IndexPQ.h:124-160):
+    // imi_nbits > 0 -> nlist = 2^(imi_M*imi_nbits), key = sum_m idx_m << (m*imi_nbits)
+    int32_t imi_M, imi_nbits;
+    const float* imi_centroids;     // [imi_M][2^imi_nbits][d/imi_M]
 };
 
 // ---------------------------------------------------------------------------
@@ -251,6 +255,145 @@ void orc_knn_L2sqr(const float* x, const float* y, size_t d, size_t nx, size_t n
 }
 
 // ---------------------------------------------------------------------------
+// MultiIndexQuantizer::search (IndexPQ.cpp:804-857) with MinSumK / SemiSortedArray
+// (IndexPQ.cpp:524-778).  Distance tables = ProductQuantizer::compute_distance_tables
+// (ProductQuantizer.cpp:438-461): sub-vectors of < 16 dims -> fvec_L2sqr per entry;
+// otherwise pairwise_L2sqr (utils.cpp:1311-1355) = (|x|^2 + |y|^2) + (-2)*sgemm, whose
+// inner product is restated as the k-ordered fmaf chain (BLAS order is vendor-defined,
+// as for the flat coarse quantizer).  SemiSortedArray sorts table entries with an
+// indirect heap whose order among EXACTLY equal values is an implementation detail;
+// here equal values are ordered by index (unpinned only for exact ties).
+// ---------------------------------------------------------------------------
+namespace {
+inline void minheap_push(size_t k, float* bh_val, int64_t* bh_ids, float val, int64_t id) {
+    bh_val--; bh_ids--;
+    size_t i = k, i_father;
+    while (i > 1) {
+        i_father = i >> 1;
+        if (!(val < bh_val[i_father])) break;
+        bh_val[i] = bh_val[i_father]; bh_ids[i] = bh_ids[i_father]; i = i_father;
+    }
+    bh_val[i] = val; bh_ids[i] = id;
+}
+inline void minheap_pop(size_t k, float* bh_val, int64_t* bh_ids) {
+    bh_val--; bh_ids--;
+    float val = bh_val[k];
+    size_t i = 1, i1, i2;
+    while (1) {
+        i1 = i << 1; i2 = i1 + 1;
+        if (i1 > k) break;
+        if (i2 == k + 1 || bh_val[i1] < bh_val[i2]) {
+            if (val < bh_val[i1]) break;
+            bh_val[i] = bh_val[i1]; bh_ids[i] = bh_ids[i1]; i = i1;
+        } else {
+            if (val < bh_val[i2]) break;
+            bh_val[i] = bh_val[i2]; bh_ids[i] = bh_ids[i2]; i = i2;
+        }
+    }
+    bh_val[i] = bh_val[k]; bh_ids[i] = bh_ids[k];
+}
+}  // namespace
+
+void orc_imi_distance_tables(const orc_index* ix, const float* x, size_t n, float* tabs) {
+    const int Mc = ix->imi_M, kc = 1 << ix->imi_nbits, dc = ix->d / Mc;
+    if (dc < 16) {
+#pragma omp parallel for
+        for (size_t i = 0; i < n; i++)
+            for (int m = 0; m < Mc; m++)
+                for (int j = 0; j < kc; j++)
+                    tabs[(i * Mc + m) * kc + j] = orc_fvec_L2sqr(
+                        x + i * ix->d + m * dc, ix->imi_centroids + ((size_t)m * kc + j) * dc, dc);
+    } else {
+        for (int m = 0; m < Mc; m++) {
+            std::vector<float> bn(kc);
+            for (int j = 0; j < kc; j++) bn[j] = orc_fvec_norm_L2sqr(ix->imi_centroids + ((size_t)m * kc + j) * dc, dc);
+#pragma omp parallel for
+            for (size_t i = 0; i < n; i++) {
+                const float* xi = x + i * ix->d + m * dc;
+                const float qn = orc_fvec_norm_L2sqr(xi, dc);
+                for (int j = 0; j < kc; j++) {
+                    const float* y = ix->imi_centroids + ((size_t)m * kc + j) * dc;
+                    float ip = 0.f;
+                    for (int c = 0; c < dc; c++) ip = fmaf(xi[c], y[c], ip);
+                    tabs[(i * Mc + m) * kc + j] = (qn + bn[j]) + (-2.0f) * ip;
+                }
+            }
+        }
+    }
+}
+
+void orc_imi_search(const orc_index* ix, const float* x, size_t n, size_t k, float* D, int64_t* I) {
+    const int Mc = ix->imi_M, kc = 1 << ix->imi_nbits, nb = ix->imi_nbits;
+    std::vector<float> tabs(n * Mc * kc);
+    orc_imi_distance_tables(ix, x, n, tabs.data());
+#pragma omp parallel
+    {
+        std::vector<std::vector<int> > perm(Mc, std::vector<int>(kc));
+        std::vector<float> hv(k * Mc + 1);
+        std::vector<int64_t> hi(k * Mc + 1), weights(Mc);
+#pragma omp for
+        for (size_t q = 0; q < n; q++) {
+            const float* t = &tabs[q * Mc * kc];
+            if (k == 1) {   // IndexPQ.cpp:815-840
+                float dis = 0;
+                int64_t label = 0;
+                for (int s = 0; s < Mc; s++) {
+                    float vmin = HUGE_VALF;
+                    int64_t lmin = -1;
+                    for (int j = 0; j < kc; j++)
+                        if (t[s * kc + j] < vmin) { vmin = t[s * kc + j]; lmin = j; }
+                    dis += vmin;
+                    label |= lmin << (s * nb);
+                }
+                D[q] = dis;
+                I[q] = label;
+                continue;
+            }
+            // MinSumK<float, SemiSortedArray<float>, false>::run (IndexPQ.cpp:690-778)
+            weights[0] = 1;
+            for (int m = 1; m < Mc; m++) weights[m] = weights[m - 1] * kc;
+            for (int m = 0; m < Mc; m++) {
+                for (int j = 0; j < kc; j++) perm[m][j] = j;
+                const float* xm = t + m * kc;
+                std::stable_sort(perm[m].begin(), perm[m].end(), [xm](int a, int b) { return xm[a] < xm[b]; });
+            }
+            auto val = [&](int m, int r) { return t[m * kc + perm[m][r]]; };
+            float* sums = D + q * k;
+            int64_t* terms = I + q * k;
+            size_t heap_size = 0;
+            float sum = 0;
+            terms[0] = 0;
+            for (int m = 0; m < Mc; m++) sum += val(m, 0);
+            sums[0] = sum;
+            for (int m = 0; m < Mc; m++)
+                minheap_push(++heap_size, hv.data(), hi.data(), sum + (val(m, 1) - val(m, 0)), weights[m]);
+            for (size_t kk = 1; kk < k; kk++) {
+                const float s2 = sums[kk] = hv[0];
+                const int64_t ti = terms[kk] = hi[0];
+                do { minheap_pop(heap_size--, hv.data(), hi.data()); } while (heap_size > 0 && hi[0] == ti);
+                int64_t ii = ti;
+                for (int m = 0; m < Mc; m++) {
+                    const int64_t nn = ii % kc;
+                    ii /= kc;
+                    if (nn + 1 >= kc) continue;
+                    minheap_push(++heap_size, hv.data(), hi.data(),
+                                 s2 + (val(m, (int)nn + 1) - val(m, (int)nn)), ti + weights[m]);
+                }
+            }
+            for (size_t kk = 0; kk < k; kk++) {   // ranks -> centroid indices
+                int64_t ii = terms[kk], ti = 0;
+                for (int m = 0; m < Mc; m++) {
+                    const int64_t nn = ii % kc;
+                    ti += weights[m] * perm[m][nn];
+                    ii /= kc;
+                }
+                terms[kk] = ti;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Product-quantizer tables (ProductQuantizer.cpp:410-436) for dsub < 16 (the
 // non-BLAS branch; BASELINE configs have dsub = 8 or 6).
 // ---------------------------------------------------------------------------
@@ -277,6 +420,21 @@ void orc_precompute_table(const orc_index* ix, float* out) {
         for (int j = 0; j < ix->ksub; j++)
             r_norms[m * ix->ksub + j] = orc_fvec_norm_L2sqr(
                 ix->pq_centroids + ((size_t)m * ix->ksub + j) * ix->dsub, ix->dsub);
+    if (ix->imi_nbits > 0) {
+        // table type 2 (IndexIVFPQ.cpp:430-457): one row per coarse SUB-centroid index i, built
+        // from the vector whose m-th part is the i-th centroid of coarse sub-quantizer m
+        const int Mc = ix->imi_M, kc = 1 << ix->imi_nbits, dc = ix->d / Mc;
+#pragma omp parallel for
+        for (int i = 0; i < kc; i++) {
+            std::vector<float> v(ix->d);
+            for (int m = 0; m < Mc; m++)
+                memcpy(&v[m * dc], ix->imi_centroids + ((size_t)m * kc + i) * dc, sizeof(float) * dc);
+            float* tab = out + (size_t)i * mk;
+            orc_compute_inner_prod_table(ix, v.data(), tab);
+            fvec_madd(mk, r_norms.data(), 2.0f, tab, tab);
+        }
+        return;
+    }
 #pragma omp parallel for
     for (int i = 0; i < ix->nlist; i++) {
         float* tab = out + (size_t)i * mk;
@@ -335,6 +493,19 @@ int64_t orc_search_knn_with_key(const orc_index* ix, size_t nx, const float* qx,
                         const float* c = ix->coarse_centroids + (size_t)key * d;
                         for (int j = 0; j < d; j++) residual[j] = qi[j] - c[j];  // Index.cpp:76-81
                         orc_compute_distance_table(ix, residual.data(), sim_table.data());
+                    } else if (ix->use_precomputed_table == 2) {
+                        // IndexIVFPQ.cpp:645-686: per coarse sub-index ki the slice of Mf sub-quantizers
+                        dis0 = cdi[ik];
+                        const int Mf = ix->M / ix->imi_M;
+                        int64_t kk = key;
+                        for (int cm = 0; cm < ix->imi_M; cm++) {
+                            const int64_t ki = kk & ((int64_t(1) << ix->imi_nbits) - 1);
+                            kk >>= ix->imi_nbits;
+                            const size_t o = (size_t)cm * Mf * ix->ksub;
+                            fvec_madd((size_t)Mf * ix->ksub,
+                                      ix->precomputed_table + ((size_t)ki * ix->M + (size_t)cm * Mf) * ix->ksub,
+                                      -2.0f, sim_table_2.data() + o, sim_table.data() + o);
+                        }
                     } else {
                         dis0 = cdi[ik];
                         fvec_madd(mk, ix->precomputed_table + (size_t)key * mk, -2.0f,
@@ -372,8 +543,11 @@ int64_t orc_search(const orc_index* ix, size_t n, const float* x, size_t nprobe,
                    float* D, int64_t* I, int canonical, int64_t* keys_out, float* cdis_out) {
     std::vector<int64_t> idx(n * nprobe);
     std::vector<float> cdis(n * nprobe);
-    orc_knn_L2sqr(x, ix->coarse_centroids, ix->d, n, ix->nlist, nprobe, cdis.data(), idx.data(),
-                  canonical, 0);
+    if (ix->imi_nbits > 0)
+        orc_imi_search(ix, x, n, nprobe, cdis.data(), idx.data());
+    else
+        orc_knn_L2sqr(x, ix->coarse_centroids, ix->d, n, ix->nlist, nprobe, cdis.data(), idx.data(),
+                      canonical, 0);
     if (keys_out) memcpy(keys_out, idx.data(), idx.size() * 8);
     if (cdis_out) memcpy(cdis_out, cdis.data(), cdis.size() * 4);
     return orc_search_knn_with_key(ix, n, x, idx.data(), cdis.data(), nprobe, k, D, I, 0, canonical);
@@ -406,12 +580,23 @@ void orc_pq_compute_codes(const orc_index* ix, const float* x, size_t n, uint8_t
 void orc_encode(const orc_index* ix, const float* x, size_t n, int64_t* assign, uint8_t* codes,
                 int canonical) {
     std::vector<float> dis(n);
-    orc_knn_L2sqr(x, ix->coarse_centroids, ix->d, n, ix->nlist, 1, dis.data(), assign, canonical, 0);
+    if (ix->imi_nbits > 0) orc_imi_search(ix, x, n, 1, dis.data(), assign);
+    else orc_knn_L2sqr(x, ix->coarse_centroids, ix->d, n, ix->nlist, 1, dis.data(), assign, canonical, 0);
     if (ix->by_residual) {
         std::vector<float> res(n * (size_t)ix->d);
 #pragma omp parallel for
         for (size_t i = 0; i < n; i++) {
             if (assign[i] < 0) { memset(&res[i * ix->d], 0, sizeof(float) * ix->d); continue; }
+            if (ix->imi_nbits > 0) {   // MultiIndexQuantizer::reconstruct (IndexPQ.cpp:860-885)
+                const int Mc = ix->imi_M, kc = 1 << ix->imi_nbits, dc = ix->d / Mc;
+                int64_t jj = assign[i];
+                for (int m = 0; m < Mc; m++) {
+                    const float* c = ix->imi_centroids + ((size_t)m * kc + (jj % kc)) * dc;
+                    jj /= kc;
+                    for (int j = 0; j < dc; j++) res[i * ix->d + m * dc + j] = x[i * ix->d + m * dc + j] - c[j];
+                }
+                continue;
+            }
             const float* c = ix->coarse_centroids + (size_t)assign[i] * ix->d;
             for (int j = 0; j < ix->d; j++) res[i * ix->d + j] = x[i * ix->d + j] - c[j];
         }

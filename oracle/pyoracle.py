@@ -22,6 +22,7 @@ class _OrcIndex(C.Structure):
         ("coarse_centroids", C.c_void_p), ("pq_centroids", C.c_void_p),
         ("precomputed_table", C.c_void_p), ("codes", C.c_void_p), ("ids", C.c_void_p),
         ("list_offsets", C.c_void_p),
+        ("imi_M", C.c_int32), ("imi_nbits", C.c_int32), ("imi_centroids", C.c_void_p),
     ]
 
 
@@ -66,17 +67,24 @@ class OracleIndex:
 
     def __init__(self, d, nlist, M, nbits, coarse_centroids, pq_centroids,
                  codes=None, ids=None, list_offsets=None, by_residual=True,
-                 use_precomputed_table=1, max_codes=0, precomputed_table=None):
+                 use_precomputed_table=1, max_codes=0, precomputed_table=None, imi_centroids=None,
+                 imi_nbits=0):
+        """imi_centroids [2][2^imi_nbits][d/2]: MultiIndexQuantizer coarse quantizer
+        (then coarse_centroids is None, nlist = 4^imi_nbits and the table mode is 2)."""
         self.d, self.nlist, self.M, self.nbits = d, nlist, M, nbits
+        self.imi_nbits = int(imi_nbits)
+        self.imi_centroids = None if imi_centroids is None else _f32(imi_centroids)
+        if self.imi_nbits:
+            coarse_centroids = np.zeros((1, d), np.float32)
         self.ksub, self.dsub, self.code_size = 1 << nbits, d // M, M
         self.by_residual = bool(by_residual)
         self.use_precomputed_table = int(use_precomputed_table)
         self.max_codes = int(max_codes)
-        self.coarse_centroids = _f32(coarse_centroids).reshape(nlist, d)
+        self.coarse_centroids = _f32(coarse_centroids).reshape(-1, d)
         self.pq_centroids = _f32(pq_centroids).reshape(M, self.ksub, self.dsub)
         self.set_lists(codes, ids, list_offsets)
         self.precomputed_table = None if precomputed_table is None else _f32(precomputed_table)
-        if self.precomputed_table is None and self.by_residual and self.use_precomputed_table == 1:
+        if self.precomputed_table is None and self.by_residual and self.use_precomputed_table in (1, 2):
             self.precomputed_table = self.precompute_table()
 
     def set_lists(self, codes, ids, list_offsets):
@@ -99,11 +107,13 @@ class OracleIndex:
         s.pq_centroids = _p(self.pq_centroids)
         s.precomputed_table = _p(getattr(self, "precomputed_table", None))
         s.codes, s.ids, s.list_offsets = _p(self.codes), _p(self.ids), _p(self.list_offsets)
+        s.imi_M, s.imi_nbits, s.imi_centroids = 2, self.imi_nbits, _p(self.imi_centroids)
         return s
 
     # --- tables -----------------------------------------------------------
     def precompute_table(self):
-        out = np.empty((self.nlist, self.M, self.ksub), np.float32)
+        rows = (1 << self.imi_nbits) if self.imi_nbits else self.nlist
+        out = np.empty((rows, self.M, self.ksub), np.float32)
         s = self._c()
         lib().orc_precompute_table(C.byref(s), _p(out))
         return out
@@ -126,6 +136,10 @@ class OracleIndex:
         n = x.shape[0]
         D = np.empty((n, nprobe), np.float32)
         I = np.empty((n, nprobe), np.int64)
+        if self.imi_nbits:
+            s = self._c()
+            lib().orc_imi_search(C.byref(s), _p(x), C.c_size_t(n), C.c_size_t(nprobe), _p(D), _p(I))
+            return D, I
         lib().orc_knn_L2sqr(_p(x), _p(self.coarse_centroids), C.c_size_t(self.d), C.c_size_t(n),
                             C.c_size_t(self.nlist), C.c_size_t(nprobe), _p(D), _p(I),
                             C.c_int(int(canonical)), C.c_int(force_path))

@@ -14,7 +14,7 @@
 //            optional xids[nb]
 //   cfg = {d, nlist, M, nbits, nt, nb, nq, nprobe, k, max_codes, n_small,
 //          kmeans_niter, pq_niter, by_residual, use_precomputed_table(-1=auto),
-//          reserved}
+//          imi_nbits (0 = IndexFlatL2 coarse quantizer, else MultiIndexQuantizer 2 x imi_nbits)}
 
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +26,7 @@
 
 #include "IndexFlat.h"
 #include "IndexIVFPQ.h"
+#include "IndexPQ.h"
 #include "utils.h"
 
 namespace {
@@ -86,7 +87,7 @@ int main(int argc, char** argv) {
     const long d = cfg[0], nlist = cfg[1], M = cfg[2], nbits = cfg[3], nt = cfg[4],
                nb = cfg[5], nq = cfg[6], nprobe = cfg[7], k = cfg[8],
                max_codes = cfg[9], n_small = cfg[10], km_niter = cfg[11],
-               pq_niter = cfg[12], by_residual = cfg[13], upt = cfg[14];
+               pq_niter = cfg[12], by_residual = cfg[13], upt = cfg[14], imi_nbits = cfg[15];
     const float* xt = (const float*)in["xt"].data.data();
     const float* xb = (const float*)in["xb"].data.data();
     const float* xq = (const float*)in["xq"].data.data();
@@ -96,7 +97,13 @@ int main(int argc, char** argv) {
     if (!g_out) { perror(argv[2]); return 1; }
 
     faiss::IndexFlatL2 coarse(d);
-    faiss::IndexIVFPQ index(&coarse, d, nlist, M, nbits);
+    faiss::MultiIndexQuantizer miq(d, 2, imi_nbits > 0 ? imi_nbits : 1);   // tests/sift1b_imi_pq.cpp:225-236
+    faiss::Index* quant = imi_nbits > 0 ? (faiss::Index*)&miq : (faiss::Index*)&coarse;
+    faiss::IndexIVFPQ index(quant, d, nlist, M, nbits);
+    if (imi_nbits > 0) {
+        index.quantizer_trains_alone = true;
+        if (km_niter > 0) miq.pq.cp.niter = km_niter;
+    }
     if (km_niter > 0) index.cp.niter = km_niter;
     if (pq_niter > 0) index.pq.cp.niter = pq_niter;
     index.by_residual = by_residual != 0;
@@ -113,11 +120,15 @@ int main(int argc, char** argv) {
     int64_t meta[4] = {index.use_precomputed_table, (int64_t)index.code_size,
                        (int64_t)index.pq.ksub, (int64_t)index.pq.dsub};
     put("meta", 'l', {4}, meta);
-    put("coarse_centroids", 'f', {(uint64_t)nlist, (uint64_t)d}, coarse.xb.data());
+    if (imi_nbits > 0)
+        put("imi_centroids", 'f', {2, miq.pq.ksub, miq.pq.dsub}, miq.pq.centroids.data());
+    else
+        put("coarse_centroids", 'f', {(uint64_t)nlist, (uint64_t)d}, coarse.xb.data());
     put("pq_centroids", 'f', {(uint64_t)M, index.pq.ksub, index.pq.dsub},
         index.pq.centroids.data());
     if (!index.precomputed_table.empty())
-        put("precomputed_table", 'f', {(uint64_t)nlist, (uint64_t)M, index.pq.ksub},
+        put("precomputed_table", 'f',
+            {(uint64_t)(index.precomputed_table.size() / (M * index.pq.ksub)), (uint64_t)M, index.pq.ksub},
             index.precomputed_table.data());
 
     // list-contiguous dump of the inverted lists (IndexIVF.h:55, IndexIVFPQ.h:43)
@@ -137,14 +148,14 @@ int main(int argc, char** argv) {
     // add path: coarse assignment of the database vectors (Index::assign)
     {
         std::vector<long> assign(nb);
-        coarse.assign(nb, xb, assign.data());
+        quant->assign(nb, xb, assign.data());
         put("xb_assign", 'l', {(uint64_t)nb}, assign.data());
     }
 
     // coarse stage (IndexIVFPQ.cpp:1073): blas path for nq >= 20
     std::vector<long> keys(nq * nprobe);
     std::vector<float> cdis(nq * nprobe);
-    coarse.search(nq, xq, nprobe, cdis.data(), keys.data());
+    quant->search(nq, xq, nprobe, cdis.data(), keys.data());
     put("keys", 'l', {(uint64_t)nq, (uint64_t)nprobe}, keys.data());
     put("coarse_dis", 'f', {(uint64_t)nq, (uint64_t)nprobe}, cdis.data());
 
@@ -172,7 +183,7 @@ int main(int argc, char** argv) {
     if (n_small > 0) {
         std::vector<long> ks(n_small * nprobe), Is(n_small * k);
         std::vector<float> cs(n_small * nprobe), Ds(n_small * k);
-        coarse.search(n_small, xq, nprobe, cs.data(), ks.data());
+        quant->search(n_small, xq, nprobe, cs.data(), ks.data());
         index.search(n_small, xq, k, Ds.data(), Is.data());
         put("small_keys", 'l', {(uint64_t)n_small, (uint64_t)nprobe}, ks.data());
         put("small_coarse_dis", 'f', {(uint64_t)n_small, (uint64_t)nprobe}, cs.data());
@@ -196,9 +207,11 @@ int main(int argc, char** argv) {
     {
         std::vector<float> qn(nq), cn(nlist);
         faiss::fvec_norms_L2sqr(qn.data(), xq, d, nq);
-        faiss::fvec_norms_L2sqr(cn.data(), coarse.xb.data(), d, nlist);
         put("q_norms", 'f', {(uint64_t)nq}, qn.data());
-        put("c_norms", 'f', {(uint64_t)nlist}, cn.data());
+        if (imi_nbits == 0) {
+            faiss::fvec_norms_L2sqr(cn.data(), coarse.xb.data(), d, nlist);
+            put("c_norms", 'f', {(uint64_t)nlist}, cn.data());
+        }
     }
 
     fclose(g_out);

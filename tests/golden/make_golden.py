@@ -66,9 +66,9 @@ def case(fn):
 
 
 def cfg(d, nlist, M, nbits, nt, nb, nq, nprobe, k, max_codes=0, n_small=0,
-        km_niter=0, pq_niter=0, by_residual=1, upt=-1):
+        km_niter=0, pq_niter=0, by_residual=1, upt=-1, imi_nbits=0):
     return np.array([d, nlist, M, nbits, nt, nb, nq, nprobe, k, max_codes, n_small,
-                     km_niter, pq_niter, by_residual, upt, 0], dtype=np.int64)
+                     km_niter, pq_niter, by_residual, upt, imi_nbits], dtype=np.int64)
 
 
 @case
@@ -142,6 +142,23 @@ def m32_long_codes():
     return cfg(128, 48, 32, 7, 5000, 3000, 30, 10, 16, pq_niter=5), xt, xb, xq, None
 
 
+@case
+def imi_sse_tables():
+    """Inverted multi-index coarse quantizer 2 x 4 bit (256 lists), coarse sub-vectors of
+    8 dims -> the reference's SSE table path (no BLAS): coarse stage bit-pinned too.
+    Table mode 2 (IndexIVFPQ.cpp:430-457,645-686), M=8 -> 4 PQ sub-quantizers per half."""
+    xt, xb, xq = gmm_case(909, 16, 40, 4000, 3000, 40, sigma=0.1)
+    return cfg(16, 256, 8, 8, 4000, 3000, 40, 12, 10, n_small=6, km_niter=8, pq_niter=6, imi_nbits=4), xt, xb, xq, None
+
+
+@case
+def imi_blas_tables():
+    """IMI 2 x 5 bit (1024 lists), coarse sub-vectors of 32 dims -> pairwise_L2sqr / sgemm
+    tables (utils.cpp:1311-1355): coarse stage pinned to rounding only.  M=16 x 8 bit."""
+    xt, xb, xq = gmm_case(1010, 64, 60, 5000, 4000, 48)
+    return cfg(64, 1024, 16, 8, 5000, 4000, 48, 24, 10, km_niter=8, pq_niter=5, imi_nbits=5), xt, xb, xq, None
+
+
 def sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -170,7 +187,7 @@ def run_case(name):
             keep[nm] = a
     if xids is not None:
         keep["xids"] = xids
-    for nm in ("meta", "coarse_centroids", "pq_centroids", "list_offsets", "codes", "ids",
+    for nm in ("meta", "coarse_centroids", "imi_centroids", "pq_centroids", "list_offsets", "codes", "ids",
                "xb_assign", "keys", "coarse_dis", "D", "I", "ncode", "D_pairs", "I_pairs",
                "small_keys", "small_coarse_dis", "small_D", "small_I", "q_norms", "c_norms"):
         if nm in out:
@@ -179,6 +196,7 @@ def run_case(name):
     if "precomputed_table" in out:
         pt = out["precomputed_table"]
         keep["precomputed_table_head"] = pt[:3]
+        keep["precomputed_table_rows"] = np.array([pt.shape[0]], np.int64)
         keep["precomputed_table_sha256"] = sha(pt)
     for nm in ("ip_table", "dis_table"):
         keep[nm + "_head"] = out[nm][:2]

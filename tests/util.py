@@ -19,6 +19,7 @@ class Case:
         c = self.z["cfg"]
         (self.d, self.nlist, self.M, self.nbits, self.nt, self.nb, self.nq, self.nprobe, self.k,
          self.max_codes, self.n_small, _, _, self.by_residual, _) = [int(v) for v in c[:15]]
+        self.imi_nbits = int(c[15]) if len(c) > 15 else 0
         self.mode = int(self.z["meta"][0])
         self.xq = self.z["xq"]
         self.xb = self.z["xb_u8"].astype(np.float32) if "xb_u8" in self.z else self.z["xb"]
@@ -30,7 +31,8 @@ class Case:
     def oracle_index(self, with_lists=True):
         z = self.z
         return pyoracle.OracleIndex(
-            self.d, self.nlist, self.M, self.nbits, z["coarse_centroids"], z["pq_centroids"],
+            self.d, self.nlist, self.M, self.nbits, z.get("coarse_centroids"), z["pq_centroids"],
+            imi_centroids=z.get("imi_centroids"), imi_nbits=self.imi_nbits,
             codes=z["codes"] if with_lists else None, ids=z["ids"] if with_lists else None,
             list_offsets=z["list_offsets"] if with_lists else None,
             by_residual=self.by_residual, use_precomputed_table=self.mode, max_codes=self.max_codes)
