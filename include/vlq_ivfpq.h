@@ -64,6 +64,13 @@ int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream);
  * (gpu/GpuIndexIVF.cu:120-150).  centroids: [nlist*d] [h|d]. */
 int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids);
 
+/* MultiIndexQuantizer coarse quantizer with 2 sub-quantizers of imi_nbits each
+ * (IndexPQ.h:124-160; "IMI2x14" of tests/sift1b_imi_pq.cpp): replaces the flat coarse
+ * centroids.  The index must have been created with nlist = 4^imi_nbits; list key =
+ * i0 | i1 << imi_nbits; the precomputed table becomes type 2 (IndexIVFPQ.cpp:430-457).
+ * centroids: [2][2^imi_nbits][d/2] = MultiIndexQuantizer::pq.centroids.  [h|d] */
+int vlq_ivfpq_set_imi_centroids(vlq_ivfpq_t h, int imi_nbits, const float* centroids);
+
 /* ProductQuantizer::centroids [M][ksub][dsub] (ProductQuantizer.h:51-60),
  * GpuIndexIVFPQ::copyFrom gpu/GpuIndexIVFPQ.cu:168-231. [h|d] */
 int vlq_ivfpq_set_pq_centroids(vlq_ivfpq_t h, const float* centroids);

@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 
 def gpu_index(case, with_lists=True):
     g = vlq.GpuIVFPQ(case.d, case.nlist, case.M, case.nbits)
-    g.set_coarse_centroids(case["coarse_centroids"])
+    if case.imi_nbits:
+        g.set_imi_centroids(case.imi_nbits, case["imi_centroids"])
+    else:
+        g.set_coarse_centroids(case["coarse_centroids"])
     g.set_pq_centroids(case["pq_centroids"])
-    g.set_search_options(by_residual=case.by_residual, use_precomputed_table=case.mode,
+    g.set_search_options(by_residual=case.by_residual, use_precomputed_table=min(case.mode, 1),
                          max_codes=case.max_codes)
     if with_lists:
         g.set_lists(case["codes"], case["ids"], case["list_offsets"])
@@ -38,10 +41,10 @@ def test_query_tables_bit_exact(case):
 
 
 def test_precomputed_table_bit_exact(case):
-    if case.mode != 1:
+    if case.mode not in (1, 2):
         pytest.skip("no precomputed table in this mode")
     g = gpu_index(case)
-    t = g.precomputed_table()
+    t = g.precomputed_table(rows=(1 << case.imi_nbits) if case.imi_nbits else None)
     assert np.array_equal(bits(t[:3]), bits(case["precomputed_table_head"]))
     assert np.array_equal(sha(t), case["precomputed_table_sha256"])
 
@@ -70,6 +73,8 @@ def test_coarse_bit_exact_vs_oracle(case):
     cdo, keyso = ox.coarse_search(case.xq, case.nprobe, canonical=True)
     assert np.array_equal(bits(cd), bits(cdo))
     assert np.array_equal(keys, keyso)
+    if case.imi_nbits and case.d // 2 < 16:   # SSE tables + MinSumK replay: pinned to the reference itself
+        assert np.array_equal(keys, case["keys"]) and np.array_equal(bits(cd), bits(case["coarse_dis"]))
     # and against the reference (BLAS summation order unpinned): to rounding
     same = keys == case["keys"]
     assert same.mean() >= 0.999

@@ -69,6 +69,16 @@ int ensure_term2(vlq_ivfpq_t h) {
     if (h->term2_valid) return VLQ_OK;
     if (!h->have_coarse || !h->have_pq) return fail(VLQ_ERR_STATE, "centroids not set");
     const size_t E = (size_t)h->M * h->ksub;
+    if (h->imi_nbits > 0) {
+        // table type 2 (IndexIVFPQ.cpp:430-457): one row per coarse sub-centroid index
+        const int64_t kc = int64_t(1) << h->imi_nbits;
+        TRY(h->term2.reserve((size_t)kc * E * sizeof(float)));
+        vlq::launch_pq_tables(h->imi_virtual.as<float>(), kc, h->d, h->pq.as<float>(), h->M, h->ksub,
+                              h->dsub, h->rnorm.as<float>(), 2, h->term2.as<float>(), h->stream);
+        HIP_TRY(hipGetLastError());
+        h->term2_valid = true;
+        return VLQ_OK;
+    }
     TRY(h->term2.reserve((size_t)h->nlist * E * sizeof(float)));
     // IndexIVFPQ::precompute_table (IndexIVFPQ.cpp:411-429)
     vlq::launch_pq_tables(h->coarse.as<float>(), h->nlist, h->d, h->pq.as<float>(), h->M, h->ksub,
@@ -117,9 +127,62 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
 }
 
 // coarse stage on device buffers: x_dev [n][d] -> cdis_dev, keys_dev [n][nprobe]
+// MultiIndexQuantizer::search (IndexPQ.cpp:804-857) for one page: the two distance tables,
+// their T smallest entries in order, then the MinSumK walk
+int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_dev, int64_t* keys_dev) {
+    const int kc = 1 << h->imi_nbits, dc = h->d / 2;
+    const int T = std::min(k, kc);
+    // workspace: 2 tables [n][kc] | sorted values 2x[n][T] | sorted ids 2x[n][T] | heap
+    const size_t b_tab = (size_t)n * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
+    const size_t b_hv = (size_t)n * 2 * k * 4, b_hi = (size_t)n * 2 * k * 8, b_sub = (size_t)n * dc * 4;
+    TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + b_sub + 256));
+    char* p = h->ws_imi.as<char>();
+    float* tab[2] = {(float*)p, (float*)(p + b_tab)};
+    p += 2 * b_tab;
+    int64_t* si[2] = {(int64_t*)p, (int64_t*)(p + b_si)};
+    p += 2 * b_si;
+    int64_t* hi = (int64_t*)p;
+    p += b_hi;
+    float* sv[2] = {(float*)p, (float*)(p + b_sv)};
+    p += 2 * b_sv;
+    float* hv = (float*)p;
+    p += b_hv;
+    float* sub = (float*)p;
+    for (int m = 0; m < 2; m++) {
+        const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
+        if (dc < 16) {
+            // compute_distance_table (ProductQuantizer.cpp:410-422): fvec_L2sqr per entry
+            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
+            vlq::launch_pq_tables(sub, n, dc, cent, 1, kc, dc, nullptr, 1, tab[m], h->stream);
+        } else {
+            // pairwise_L2sqr (utils.cpp:1311-1355): (|x|^2 + |y|^2) - 2 <x,y>
+            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
+            TRY(h->ws_qn.reserve((size_t)n * 4));
+            vlq::launch_row_norms(sub, n, dc, h->ws_qn.as<float>(), h->stream);
+            vlq::launch_coarse_distances(sub, cent, h->ws_qn.as<float>(), h->imi_norm.as<float>() + (size_t)m * kc,
+                                         tab[m], n, kc, dc, h->stream);
+        }
+        vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream);
+    }
+    vlq::launch_imi_minsum(sv[0], si[0], sv[1], si[1], T, n, k, kc, h->imi_nbits, hv, hi, cdis_dev, keys_dev,
+                           h->stream);
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
 int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
                int64_t* keys_dev) {
     StageTimer tm(h, 0);
+    if (h->imi_nbits > 0) {
+        const int64_t kc = int64_t(1) << h->imi_nbits;
+        const int64_t page = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)((size_t(1) << 27) / (size_t)kc)));
+        for (int64_t i0 = 0; i0 < n; i0 += page) {
+            const int64_t ni = std::min(page, n - i0);
+            TRY(imi_page(h, ni, x_dev + i0 * h->d, nprobe, cdis_dev + i0 * nprobe, keys_dev + i0 * nprobe));
+        }
+        tm.stop();
+        return VLQ_OK;
+    }
     const int64_t page = query_page(h);
     // knn_L2sqr dispatch (utils.cpp:935-946): small batches bypass the GEMM formulation
     const bool direct = (h->d % 4 == 0) && n < 20;
@@ -138,6 +201,8 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
     TRY(ensure_term2(h));
     const size_t E = (size_t)h->M * h->ksub;
     const int table_mode = !h->by_residual ? 2 : (h->use_precomputed_table == 1 ? 1 : 0);
+    if (h->imi_nbits > 0 && table_mode == 0)
+        return fail(VLQ_ERR_UNSUPPORTED, "multi-index coarse quantizer without the precomputed table (type 2) is not built");
     const int64_t page = 32768;
     // M=16 x 8 bit x d=128 in table mode 1: the scan kernel builds the per-query table itself
     const bool fused_tables = table_mode == 1 && h->M == 16 && h->ksub == 256 && h->dsub == 8;
@@ -173,11 +238,12 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.nprobe = nprobe; a.k = k; a.M = h->M; a.ksub = h->ksub; a.dsub = h->dsub; a.d = h->d;
         a.nlist = h->nlist;
         a.table_mode = table_mode;
+        a.imi_nbits = h->imi_nbits;
         a.max_codes = h->max_codes;
         a.store_pairs = store_pairs;
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
         if (fast16) {
-            if (ni >= 1024) {
+            if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);   // query ordering is booked with the table stage
                 // run queries that share their nearest centroid next to each other (L2 reuse)
                 TRY(h->ws_hist.reserve(((size_t)h->nlist + 1) * sizeof(int)));
@@ -282,7 +348,8 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats};
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats, &h->imi_cent,
+                      &h->imi_norm, &h->imi_virtual, &h->ws_imi};
     for (auto b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -307,6 +374,37 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     vlq::launch_row_norms(h->coarse.as<float>(), h->nlist, h->d, h->cnorm.as<float>(), h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_coarse = true;
+    h->imi_nbits = 0;
+    h->term2_valid = false;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_imi_centroids(vlq_ivfpq_t h, int imi_nbits, const float* centroids) {
+    if (!h || !centroids) return fail(VLQ_ERR_INVALID, "null argument");
+    if (imi_nbits < 1 || imi_nbits > 15) return fail(VLQ_ERR_INVALID, "imi_nbits=%d outside 1..15", imi_nbits);
+    if ((int64_t)h->nlist != (int64_t(1) << (2 * imi_nbits)))
+        return fail(VLQ_ERR_INVALID, "nlist=%d must be 4^imi_nbits for a 2 x %d-bit multi-index", h->nlist, imi_nbits);
+    if (h->d % 2 != 0 || h->M % 2 != 0)   // IndexIVFPQ.cpp:404: pq.M % miq->pq.M == 0
+        return fail(VLQ_ERR_INVALID, "d and M must be even for a 2-way multi-index");
+    TRY(set_dev(h));
+    const int64_t kc = int64_t(1) << imi_nbits;
+    const int dc = h->d / 2;
+    const size_t bytes = (size_t)2 * kc * dc * sizeof(float);
+    TRY(h->imi_cent.reserve(bytes));
+    TRY(h->imi_norm.reserve((size_t)2 * kc * sizeof(float)));
+    TRY(h->imi_virtual.reserve((size_t)kc * h->d * sizeof(float)));
+    std::vector<float> hc((size_t)2 * kc * dc), hv((size_t)kc * h->d);
+    HIP_TRY(hipMemcpy(hc.data(), centroids, bytes, hipMemcpyDefault));
+    for (int64_t i = 0; i < kc; i++)      // IndexIVFPQ.cpp:440-448
+        for (int m = 0; m < 2; m++)
+            memcpy(&hv[(size_t)i * h->d + m * dc], &hc[((size_t)m * kc + i) * dc], sizeof(float) * dc);
+    HIP_TRY(hipMemcpyAsync(h->imi_cent.p, hc.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->imi_virtual.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, h->stream));
+    vlq::launch_row_norms(h->imi_cent.as<float>(), 2 * kc, dc, h->imi_norm.as<float>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->imi_nbits = imi_nbits;
     h->have_coarse = true;
     h->term2_valid = false;
     return VLQ_OK;
@@ -478,7 +576,8 @@ int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out) {
         return fail(VLQ_ERR_STATE, "precomputed table not in use");
     TRY(set_dev(h));
     TRY(ensure_term2(h));
-    HIP_TRY(hipMemcpyAsync(out, h->term2.p, (size_t)h->nlist * h->M * h->ksub * 4, hipMemcpyDefault, h->stream));
+    const size_t rows = h->imi_nbits > 0 ? (size_t(1) << h->imi_nbits) : (size_t)h->nlist;
+    HIP_TRY(hipMemcpyAsync(out, h->term2.p, rows * h->M * h->ksub * 4, hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return VLQ_OK;
 }
@@ -531,9 +630,10 @@ int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, 
     TRY(h->ws_misc.reserve((size_t)n * 4));
     // quantizer->assign (IndexIVFPQ.cpp:205) = 1-NN search
     TRY(coarse_dev(h, n, (const float*)xd, 1, h->ws_misc.as<float>(), (int64_t*)ad));
-    vlq::launch_residual_encode((const float*)xd, n, h->d, h->coarse.as<float>(), (const int64_t*)ad,
-                                h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub,
-                                (uint8_t*)cd, h->stream);
+    vlq::launch_residual_encode((const float*)xd, n, h->d,
+                                h->imi_nbits > 0 ? h->imi_cent.as<float>() : h->coarse.as<float>(),
+                                (const int64_t*)ad, h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub,
+                                (uint8_t*)cd, h->stream, h->imi_nbits);
     HIP_TRY(hipGetLastError());
     return finish_outputs(h, copy_a, assign, ad, (size_t)n * 8, copy_c, codes, cd, (size_t)n * h->M);
 }

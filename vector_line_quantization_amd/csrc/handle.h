@@ -82,6 +82,10 @@ struct vlq_ivfpq_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
 
     DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off;
+    // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,
+    // and the kc virtual full vectors whose term2 rows make table type 2
+    int imi_nbits = 0;
+    DevBuf imi_cent, imi_norm, imi_virtual, ws_imi;
     bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
     std::vector<int64_t> h_list_off;
 

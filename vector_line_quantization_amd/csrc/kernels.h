@@ -50,6 +50,7 @@ struct ScanArgs {
     int table_mode;              // 0: by_residual, no table; 1: by_residual + term2; 2: not by_residual
     int64_t max_codes;
     int store_pairs;
+    int imi_nbits = 0;           // > 0: table mode 2 -- key = i0 | i1 << imi_nbits, term2 rows per coarse SUB-index
     const int* qorder = nullptr; // optional processing order of the queries (scan16 only)
     int xcd_chunk = 0;           // set by the launcher
 };
@@ -60,12 +61,24 @@ void launch_scan16(const ScanArgs& a, hipStream_t s);
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s);
 
+// out[i][0..dc) = x[i][col0 .. col0+dc)
+void launch_gather_cols(const float* x, int64_t n, int d, int col0, int dc, float* out, hipStream_t s);
+
+// MultiIndexQuantizer::search for 2 sub-quantizers (IndexPQ.cpp:804-857): sorted[m] =
+// the T smallest entries of the m-th distance table, ascending, as (value, index);
+// replays MinSumK (IndexPQ.cpp:690-778) per query.  heap_* = scratch [nq][2*k].
+void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, const int64_t* si1, int T,
+                       int64_t nq, int k, int kc, int imi_nbits, float* heap_val, int64_t* heap_id,
+                       float* sums, int64_t* keys, hipStream_t s);
+
 // out[m][c][j] = in[m][j][c]
 void launch_transpose_pq(const float* in, int M, int ksub, int dsub, float* out, hipStream_t s);
 
 // encode path (IndexIVFPQ.cpp:192-231, ProductQuantizer.cpp:311-336)
+// imi_nbits > 0: `coarse` is the IMI codebook [2][2^imi_nbits][d/2] and the centroid of key
+// is the concatenation of its two sub-centroids (MultiIndexQuantizer::reconstruct)
 void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,
                             const int64_t* assign, int by_residual, const float* cent, int M,
-                            int ksub, int dsub, uint8_t* codes, hipStream_t s);
+                            int ksub, int dsub, uint8_t* codes, hipStream_t s, int imi_nbits = 0);
 
 }  // namespace vlq

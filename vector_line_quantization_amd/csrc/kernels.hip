@@ -612,9 +612,20 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a, int nbuf, int lut
                 }
             } else if (a.table_mode == 1) {
                 dis0 = cq[ik];
-                const float* t2 = a.term2 + key * E;
-                for (int e = t; e < E; e += 256)
-                    L[e] = __fadd_rn(t2[e], __fmul_rn(-2.f, qt[e]));
+                if (a.imi_nbits > 0) {
+                    // table type 2 (IndexIVFPQ.cpp:645-686): sub-quantizer m takes its row from the
+                    // coarse sub-index of the half it belongs to
+                    const int Mf = a.M / 2;
+                    const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
+                    for (int e = t; e < E; e += 256) {
+                        const int64_t ki = (e / a.ksub) < Mf ? ki0 : ki1;
+                        L[e] = __fadd_rn(a.term2[ki * E + e], __fmul_rn(-2.f, qt[e]));
+                    }
+                } else {
+                    const float* t2 = a.term2 + key * E;
+                    for (int e = t; e < E; e += 256)
+                        L[e] = __fadd_rn(t2[e], __fmul_rn(-2.f, qt[e]));
+                }
             } else if (a.table_mode == 0) {
                 // residual tables: compute_residual + compute_distance_table
                 // (IndexIVFPQ.cpp:636-637)
@@ -747,6 +758,108 @@ void launch_scan(const ScanArgs& a, hipStream_t s) {
     else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
 }
 
+__global__ void gather_cols_kernel(const float* __restrict__ x, int64_t n, int d, int col0, int dc,
+                                   float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * dc) return;
+    out[e] = x[(e / dc) * d + col0 + (e % dc)];
+}
+
+void launch_gather_cols(const float* x, int64_t n, int d, int col0, int dc, float* out, hipStream_t s) {
+    if (n <= 0) return;
+    const int64_t tot = n * dc;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, n, d,
+                       col0, dc, out);
+}
+
+// ---------------------------------------------------------------------------
+// MinSumK replay (IndexPQ.cpp:690-778), M = 2 terms: the k smallest sums v0[r0] + v1[r1]
+// in the order and with the float values the reference's heap walk produces: the first sum
+// is (0 + v0[0]) + v1[0]; every later one is its predecessor's sum plus the DIFFERENCE of
+// consecutive sorted table entries, so the values are path dependent and have to be
+// replayed step by step.  One thread per query; binary min-heap (Heap.h:89-143 with CMin)
+// of at most 2k entries in a global scratch row.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void minheap_push_dev(int k, float* bh_val, int64_t* bh_ids, float val, int64_t id) {
+    bh_val--; bh_ids--;
+    int i = k, i_father;
+    while (i > 1) {
+        i_father = i >> 1;
+        if (!(val < bh_val[i_father])) break;
+        bh_val[i] = bh_val[i_father]; bh_ids[i] = bh_ids[i_father]; i = i_father;
+    }
+    bh_val[i] = val; bh_ids[i] = id;
+}
+__device__ __forceinline__ void minheap_pop_dev(int k, float* bh_val, int64_t* bh_ids) {
+    bh_val--; bh_ids--;
+    const float val = bh_val[k];
+    int i = 1, i1, i2;
+    while (1) {
+        i1 = i << 1; i2 = i1 + 1;
+        if (i1 > k) break;
+        if (i2 == k + 1 || bh_val[i1] < bh_val[i2]) {
+            if (val < bh_val[i1]) break;
+            bh_val[i] = bh_val[i1]; bh_ids[i] = bh_ids[i1]; i = i1;
+        } else {
+            if (val < bh_val[i2]) break;
+            bh_val[i] = bh_val[i2]; bh_ids[i] = bh_ids[i2]; i = i2;
+        }
+    }
+    bh_val[i] = bh_val[k]; bh_ids[i] = bh_ids[k];
+}
+
+__global__ void imi_minsum_kernel(const float* __restrict__ sv0, const int64_t* __restrict__ si0,
+                                  const float* __restrict__ sv1, const int64_t* __restrict__ si1, int T,
+                                  int64_t nq, int k, int kc, int imi_nbits, float* __restrict__ heap_val,
+                                  int64_t* __restrict__ heap_id, float* __restrict__ sums,
+                                  int64_t* __restrict__ keys) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float* v0 = sv0 + q * T;
+    const float* v1 = sv1 + q * T;
+    const int64_t* i0 = si0 + q * T;
+    const int64_t* i1 = si1 + q * T;
+    float* out_s = sums + q * k;
+    int64_t* out_k = keys + q * k;
+    if (k == 1) {   // IndexPQ.cpp:815-840: minimum of each table (first minimum), dis = (0 + m0) + m1
+        out_s[0] = __fadd_rn(__fadd_rn(0.f, v0[0]), v1[0]);
+        out_k[0] = i0[0] | (i1[0] << imi_nbits);
+        return;
+    }
+    float* hv = heap_val + q * 2 * k;
+    int64_t* hi = heap_id + q * 2 * k;
+    int hs = 0;
+    // terms are encoded as r0 + r1 * kc over the RANKS; translated to indices on output
+    float sum = __fadd_rn(__fadd_rn(0.f, v0[0]), v1[0]);
+    out_s[0] = sum;
+    out_k[0] = i0[0] | (i1[0] << imi_nbits);
+    if (T > 1) {
+        minheap_push_dev(++hs, hv, hi, __fadd_rn(sum, __fsub_rn(v0[1], v0[0])), 1);
+        minheap_push_dev(++hs, hv, hi, __fadd_rn(sum, __fsub_rn(v1[1], v1[0])), (int64_t)kc);
+    }
+    for (int kk = 1; kk < k; kk++) {
+        if (hs == 0) { out_s[kk] = 3.402823466e+38f; out_k[kk] = -1; continue; }   // fewer than k cells
+        const float s2 = hv[0];
+        const int64_t ti = hi[0];
+        const int r0 = (int)(ti % kc), r1 = (int)(ti / kc);
+        out_s[kk] = s2;
+        out_k[kk] = i0[r0] | (i1[r1] << imi_nbits);
+        do { minheap_pop_dev(hs--, hv, hi); } while (hs > 0 && hi[0] == ti);
+        if (r0 + 1 < kc && r0 + 1 < T)
+            minheap_push_dev(++hs, hv, hi, __fadd_rn(s2, __fsub_rn(v0[r0 + 1], v0[r0])), ti + 1);
+        if (r1 + 1 < kc && r1 + 1 < T)
+            minheap_push_dev(++hs, hv, hi, __fadd_rn(s2, __fsub_rn(v1[r1 + 1], v1[r1])), ti + kc);
+    }
+}
+
+void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, const int64_t* si1, int T,
+                       int64_t nq, int k, int kc, int imi_nbits, float* heap_val, int64_t* heap_id,
+                       float* sums, int64_t* keys, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(imi_minsum_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, sv0, si0, sv1,
+                       si1, T, nq, k, kc, imi_nbits, heap_val, heap_id, sums, keys);
+}
+
 __global__ void transpose_pq_kernel(const float* __restrict__ in, int M, int ksub, int dsub,
                                     float* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -773,7 +886,7 @@ void launch_transpose_pq(const float* in, int M, int ksub, int dsub, float* out,
 __global__ __launch_bounds__(256) void encode_kernel(
     const float* __restrict__ x, int64_t n, int d, const float* __restrict__ coarse,
     const int64_t* __restrict__ assign, int by_residual, const float* __restrict__ cent, int M,
-    int ksub, int dsub, uint8_t* __restrict__ codes) {
+    int ksub, int dsub, uint8_t* __restrict__ codes, int imi_nbits) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][d]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + wave;
@@ -782,7 +895,15 @@ __global__ __launch_bounds__(256) void encode_kernel(
     const int64_t key = assign ? assign[v] : -1;
     for (int c = lane; c < d; c += 64) {
         float xv = x[v * d + c];
-        if (by_residual) xv = key < 0 ? 0.f : __fsub_rn(xv, coarse[key * d + c]);   // IndexIVFPQ.cpp:219-225
+        if (by_residual) {   // IndexIVFPQ.cpp:219-225
+            if (key < 0) xv = 0.f;
+            else if (imi_nbits > 0) {
+                const int dc = d >> 1, m = c / dc;
+                const int64_t kc = int64_t(1) << imi_nbits;
+                const int64_t idx = m == 0 ? (key & (kc - 1)) : (key >> imi_nbits);
+                xv = __fsub_rn(xv, coarse[((int64_t)m * kc + idx) * dc + (c - m * dc)]);
+            } else xv = __fsub_rn(xv, coarse[key * d + c]);
+        }
         r[c] = xv;
     }
     __builtin_amdgcn_wave_barrier();
@@ -809,11 +930,11 @@ __global__ __launch_bounds__(256) void encode_kernel(
 
 void launch_residual_encode(const float* x, int64_t n, int d, const float* coarse,
                             const int64_t* assign, int by_residual, const float* cent, int M,
-                            int ksub, int dsub, uint8_t* codes, hipStream_t s) {
+                            int ksub, int dsub, uint8_t* codes, hipStream_t s, int imi_nbits) {
     if (n <= 0) return;
     const size_t smem = (size_t)4 * d * sizeof(float);
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), smem, s, x, n, d,
-                       coarse, assign, by_residual, cent, M, ksub, dsub, codes);
+                       coarse, assign, by_residual, cent, M, ksub, dsub, codes, imi_nbits);
 }
 
 }  // namespace vlq

@@ -71,9 +71,21 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         // first live probe at or after p; returns its index (or np_eff)
         while (p < np_eff && pm.pkey[p] < 0) p++;
         if (p < np_eff) {
-            const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)pm.pkey[p] * E);
+            const int64_t key = pm.pkey[p];
+            if (a.imi_nbits > 0) {
+                // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
+                // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
+                const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
 #pragma unroll
-            for (int i = 0; i < NI; i++) t2r[i] = src[i * NT + t];
+                for (int i = 0; i < NI; i++) {
+                    const int64_t ki = (NW * i + wave) < 8 ? ki0 : ki1;
+                    t2r[i] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i * NT + t];
+                }
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)key * E);
+#pragma unroll
+                for (int i = 0; i < NI; i++) t2r[i] = src[i * NT + t];
+            }
             if ((uint32_t)t < pm.plen[p])
                 c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
         }

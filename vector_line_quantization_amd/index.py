@@ -56,6 +56,10 @@ class GpuIVFPQ:
         p, _k = _ptr(c, np.float32)
         check(lib().vlq_ivfpq_set_coarse_centroids(self._h, p))
 
+    def set_imi_centroids(self, imi_nbits, c):
+        p, _k = _ptr(c, np.float32)
+        check(lib().vlq_ivfpq_set_imi_centroids(self._h, C.c_int(imi_nbits), p))
+
     def set_pq_centroids(self, c):
         p, _k = _ptr(c, np.float32)
         check(lib().vlq_ivfpq_set_pq_centroids(self._h, p))
@@ -156,8 +160,8 @@ class GpuIVFPQ:
                                            out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def precomputed_table(self):
-        out = np.empty((self.nlist, self.M, self.ksub), np.float32)
+    def precomputed_table(self, rows=None):
+        out = np.empty((rows or self.nlist, self.M, self.ksub), np.float32)
         check(lib().vlq_ivfpq_get_precomputed_table(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
