@@ -9,6 +9,7 @@
 
 #include "IndexFlat.h"
 #include "IndexIVF.h"
+#include "IndexPQ.h"
 #include "ProductQuantizer.h"
 
 namespace faiss {
@@ -79,10 +80,12 @@ struct IndexIVFPQ : IndexIVF {
   /// precompute_table (IndexIVFPQ.cpp:392-459), flat-L2 quantizer: table type 1,
   /// computed on the device and mirrored into `precomputed_table`
   void precompute_table() {
-    if (use_precomputed_table == 0) use_precomputed_table = 1;
-    FAISS_THROW_IF_NOT_MSG(use_precomputed_table == 1, "table type 2 (IMI) is not built");
+    const MultiIndexQuantizer* miq = dynamic_cast<const MultiIndexQuantizer*>(quantizer);
+    if (use_precomputed_table == 0)      // choose the type of table (IndexIVFPQ.cpp:396-408)
+      use_precomputed_table = (miq && pq.M % miq->pq.M == 0) ? 2 : 1;
+    FAISS_THROW_IF_NOT_MSG((use_precomputed_table == 2) == (miq != nullptr), "table type does not match the quantizer");
     sync_(false);
-    precomputed_table.resize(nlist * pq.M * pq.ksub);
+    precomputed_table.resize((miq ? miq->pq.ksub : nlist) * pq.M * pq.ksub);
     VLQ_CHECK(vlq_ivfpq_get_precomputed_table(h_, precomputed_table.data()));
   }
 
@@ -158,15 +161,17 @@ struct IndexIVFPQ : IndexIVF {
   }
   void sync_(bool with_lists) const {
     const IndexFlat* flat = dynamic_cast<const IndexFlat*>(quantizer);
-    FAISS_THROW_IF_NOT_MSG(flat && flat->metric_type == METRIC_L2,
-                           "only an IndexFlatL2 coarse quantizer is built (as GpuIndexIVF::copyFrom, gpu/GpuIndexIVF.cu:131-133)");
+    const MultiIndexQuantizer* miq = dynamic_cast<const MultiIndexQuantizer*>(quantizer);
+    FAISS_THROW_IF_NOT_MSG((flat && flat->metric_type == METRIC_L2) || miq,
+                           "coarse quantizer must be an IndexFlatL2 or a MultiIndexQuantizer");
     if (!h_) {
       VLQ_CHECK(vlq_ivfpq_create(&h_, device, d, (int)nlist, (int)pq.M, (int)pq.nbits));
       hdirty_ = ldirty_ = true;
     }
     if (hdirty_) {
-      FAISS_THROW_IF_NOT(flat->ntotal == (idx_t)nlist);
-      VLQ_CHECK(vlq_ivfpq_set_coarse_centroids(h_, flat->xb.data()));
+      FAISS_THROW_IF_NOT(quantizer->ntotal == (idx_t)nlist);
+      if (miq) VLQ_CHECK(vlq_ivfpq_set_imi_centroids(h_, (int)miq->pq.nbits, miq->pq.centroids.data()));
+      else VLQ_CHECK(vlq_ivfpq_set_coarse_centroids(h_, flat->xb.data()));
       VLQ_CHECK(vlq_ivfpq_set_pq_centroids(h_, pq.centroids.data()));
       hdirty_ = false;
     }

@@ -113,6 +113,29 @@ int main() {
     }
   }
 
+  // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of
+  // tests/sift1b_imi_pq.cpp:225-236): quantizer_trains_alone, table type 2
+  {
+    faiss::MultiIndexQuantizer miq(d, 2, 3);                       // 2 x 3 bit = 64 cells
+    faiss::IndexIVFPQ imi(&miq, d, 64, 16, 8);
+    imi.quantizer_trains_alone = true;
+    imi.train(nt, trainvecs.data());
+    imi.add(nb, database.data());
+    imi.nprobe = 12;
+    std::vector<faiss::Index::idx_t> inns((size_t)k * nq);
+    std::vector<float> idis((size_t)k * nq);
+    imi.search(nq, queries.data(), k, idis.data(), inns.data());
+    int i_ok = 0;
+    for (int q = 0; q < nq; q++)
+      for (int i = 0; i < k; i++)
+        if (inns[q * k + i] == gt_nns[q]) i_ok++;
+    printf("part 2c (IMI): n_ok = %d of %d (bar %d), table type %d, table rows %zu\n", i_ok, nq, (int)(nq * 0.4),
+           imi.use_precomputed_table, imi.precomputed_table.size() / (16 * 256));
+    EXPECT(i_ok > nq * 0.4);
+    EXPECT(imi.use_precomputed_table == 2 && imi.precomputed_table.size() == (size_t)8 * 16 * 256);
+    EXPECT(miq.ntotal == 64);
+  }
+
   // part 3: error behaviour (FAISS_THROW_* -> FaissException)
   bool threw = false;
   try { faiss::IndexIVFPQ bad(&coarse_quantizer, d, ncentroids, 16, 9); } catch (const faiss::FaissException&) { threw = true; }
