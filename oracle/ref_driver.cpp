@@ -9,7 +9,7 @@
 // (Index.h:60-188, IndexIVFPQ.h:29-164).  The reference cannot travel to the GPU
 // box; the fixtures (data) do.
 //
-// usage: ref_driver <in.bin> <out.bin>
+// usage: ref_driver <in.bin> <out.bin> [index_file]   (index_file: faiss::write_index of the index)
 //   in.bin : tagged arrays  cfg[int64 x 16], xt[nt*d], xb[nb*d], xq[nq*d],
 //            optional xids[nb]
 //   cfg = {d, nlist, M, nbits, nt, nb, nq, nprobe, k, max_codes, n_small,
@@ -27,6 +27,7 @@
 #include "IndexFlat.h"
 #include "IndexIVFPQ.h"
 #include "IndexPQ.h"
+#include "index_io.h"
 #include "utils.h"
 
 namespace {
@@ -81,7 +82,7 @@ void put(const char* name, char dtype, std::vector<uint64_t> dims, const void* p
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc != 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s in.bin out.bin [index_file]\n", argv[0]); return 1; }
     auto in = read_tagged(argv[1]);
     const int64_t* cfg = (const int64_t*)in["cfg"].data.data();
     const long d = cfg[0], nlist = cfg[1], M = cfg[2], nbits = cfg[3], nt = cfg[4],
@@ -214,6 +215,7 @@ int main(int argc, char** argv) {
         }
     }
 
+    if (argc == 4) faiss::write_index(&index, argv[3]);   // index_io.cpp:240-355
     fclose(g_out);
     fprintf(stderr, "ref_driver: use_precomputed_table=%d ncode=%ld ntotal=%ld\n",
             index.use_precomputed_table, (long)ncode, (long)index.ntotal);

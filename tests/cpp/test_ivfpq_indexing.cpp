@@ -11,6 +11,7 @@
 #include "faiss_amd/IndexIVFPQ.h"
 #include "faiss_amd/gpu/GpuIndexIVFPQ.h"
 #include "faiss_amd/gpu/StandardGpuResources.h"
+#include "faiss_amd/index_io.h"
 
 #define EXPECT(c) do { if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
 
@@ -134,6 +135,23 @@ int main() {
     EXPECT(i_ok > nq * 0.4);
     EXPECT(imi.use_precomputed_table == 2 && imi.precomputed_table.size() == (size_t)8 * 16 * 256);
     EXPECT(miq.ntotal == 64);
+  }
+
+  // part 2d: write_index / read_index (the drivers cache *_populated_index.faissindex,
+  // tests/sift1b_imi_pq.cpp:238-293): a reloaded index answers identically
+  {
+    const char* fn = "/tmp/vlq_test_index.faissindex";
+    faiss::write_index(&index, fn);
+    faiss::Index* loaded = faiss::read_index(fn);
+    faiss::IndexIVFPQ* liv = dynamic_cast<faiss::IndexIVFPQ*>(loaded);
+    EXPECT(liv != nullptr && liv->use_precomputed_table == 1 && liv->ntotal == index.ntotal);
+    liv->nprobe = 5;
+    std::vector<faiss::Index::idx_t> lnns((size_t)k * nq);
+    std::vector<float> ldis((size_t)k * nq);
+    loaded->search(nq, queries.data(), k, ldis.data(), lnns.data());
+    EXPECT(lnns == nns && ldis == dis);
+    delete loaded;
+    remove(fn);
   }
 
   // part 3: error behaviour (FAISS_THROW_* -> FaissException)

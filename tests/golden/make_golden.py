@@ -175,8 +175,10 @@ def run_case(name):
         if xids is not None:
             arrs["xids"] = xids
         write_tagged(fin, arrs)
-        subprocess.check_call([os.path.join(ROOT, "oracle/_ref/ref_driver"), fin, fout], env=env)
+        fidx = os.path.join(td, "index.faissindex")
+        subprocess.check_call([os.path.join(ROOT, "oracle/_ref/ref_driver"), fin, fout, fidx], env=env)
         out = read_tagged(fout)
+        index_file = np.fromfile(fidx, dtype=np.uint8)
 
     keep = {"cfg": c, "xq": xq}
     # inputs: store compactly when exactly byte-valued
@@ -201,6 +203,8 @@ def run_case(name):
     for nm in ("ip_table", "dis_table"):
         keep[nm + "_head"] = out[nm][:2]
         keep[nm + "_sha256"] = sha(out[nm])
+    if name in ("tiny_padding", "imi_sse_tables"):   # the reference's on-disk format (write_index), as data
+        keep["faissindex_file"] = index_file
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **keep)
     print("%-18s %8.1f KB  ncode=%d mode=%d" % (name, os.path.getsize(path) / 1024.0,
