@@ -3,6 +3,8 @@
 // gpu/GpuIndexFlat.h:27-49) over the MI355X library, including the fork's VLQ
 // constructor (nedge, nLambda) with its train / add / search path (vlq_line.h).
 #pragma once
+#include <fstream>
+#include <string>
 #include <vector>
 
 #include "compat.h"
@@ -246,6 +248,115 @@ class GpuIndexIVFPQ : public GpuIndex {
     return std::vector<long>(v.begin(), v.end());
   }
   vlq_ivfpq_t handle() const { return h_; }
+
+  /// GpuIndexIVFPQ::merge (gpu/GpuIndexIVFPQ.cu:1519-1591): nns / dist hold the per-process
+  /// results [nprocess][nq][k] (as gathered by the fork's MPI drivers); host buffers
+  void merge(faiss::Index::idx_t* nns, float* dist, int k, int nq, int nprocess, float* distances,
+             faiss::Index::idx_t* labels) const {
+    const size_t np = (size_t)nprocess * nq * k, no = (size_t)nq * k;
+    void *dD = nullptr, *dI = nullptr, *oD = nullptr, *oI = nullptr;
+    auto chk = [](hipError_t e) { if (e != hipSuccess) FAISS_THROW_FMT("HIP error %s", hipGetErrorString(e)); };
+    chk(hipSetDevice(device_));
+    chk(hipMalloc(&dD, np * 4)); chk(hipMalloc(&dI, np * 8)); chk(hipMalloc(&oD, no * 4)); chk(hipMalloc(&oI, no * 8));
+    hipStream_t st = resources_->getDefaultStream(device_);
+    chk(hipMemcpyAsync(dD, dist, np * 4, hipMemcpyHostToDevice, st));
+    chk(hipMemcpyAsync(dI, nns, np * 8, hipMemcpyHostToDevice, st));
+    const int rc = vlq_merge_topk(device_, (void*)st, nq, k, nprocess, (const float*)dD, (const int64_t*)dI,
+                                  (float*)oD, (int64_t*)oI);
+    if (rc == VLQ_OK) {
+      chk(hipMemcpyAsync(distances, oD, no * 4, hipMemcpyDeviceToHost, st));
+      chk(hipMemcpyAsync(labels, oI, no * 8, hipMemcpyDeviceToHost, st));
+      chk(hipStreamSynchronize(st));
+    }
+    (void)hipFree(dD); (void)hipFree(dI); (void)hipFree(oD); (void)hipFree(oI);
+    VLQ_CHECK(rc);
+  }
+
+  // ---- the fork's raw VLQ files (gpu/GpuIndexIVFPQ.cu:1731-1844) -------------------------
+  /// <name>.ppqt = centroids | pq centroids | edgeInfo | edgeDistInfo | lambdaInfo | constInfo
+  void writeCodebookToFile(const std::string& name) {
+    FAISS_THROW_IF_NOT_MSG(line_ && is_trained, "VLQ index not trained");
+    std::ofstream f((name + ".ppqt").c_str(), std::ofstream::out | std::ofstream::binary);
+    FAISS_THROW_IF_NOT_MSG(f.good(), "cannot open .ppqt for writing");
+    std::vector<float> zeros(nLambda_, 0.f);   // constInfo_: the abandoned "constq" experiment (:722-731)
+    f.write((const char*)coarse_.data(), coarse_.size() * sizeof(float));
+    f.write((const char*)pqCentroids_.data(), pqCentroids_.size() * sizeof(float));
+    f.write((const char*)edgeInfo_, (size_t)nlist_ * numedge_ * sizeof(int));
+    f.write((const char*)edgeDistInfo_, (size_t)nlist_ * numedge_ * sizeof(float));
+    f.write((const char*)lambdaInfo_, nLambda_ * sizeof(float));
+    f.write((const char*)zeros.data(), nLambda_ * sizeof(float));
+  }
+  void readCodebookFromFile(const std::string& name) {
+    FAISS_THROW_IF_NOT_MSG(line_, "not a VLQ index");
+    std::ifstream f((name + ".ppqt").c_str(), std::ifstream::in | std::ifstream::binary);
+    FAISS_THROW_IF_NOT_MSG(f.good(), "cannot open .ppqt");
+    coarse_.resize((size_t)nlist_ * d);
+    pqCentroids_.resize((size_t)(1 << bitsPerCode_) * d);
+    f.read((char*)coarse_.data(), coarse_.size() * sizeof(float));
+    f.read((char*)pqCentroids_.data(), pqCentroids_.size() * sizeof(float));
+    f.read((char*)edgeInfo_, (size_t)nlist_ * numedge_ * sizeof(int));
+    f.read((char*)edgeDistInfo_, (size_t)nlist_ * numedge_ * sizeof(float));
+    f.read((char*)lambdaInfo_, nLambda_ * sizeof(float));
+    FAISS_THROW_IF_NOT_MSG(f.good(), ".ppqt file too short");
+    VLQ_CHECK(vlq_line_set_coarse_centroids(line_, coarse_.data()));
+    VLQ_CHECK(vlq_line_set_graph(line_, edgeInfo_, edgeDistInfo_));
+    VLQ_CHECK(vlq_line_set_lambda_codebook(line_, lambdaInfo_));
+    VLQ_CHECK(vlq_line_set_pq_centroids(line_, pqCentroids_.data()));
+    is_trained = true;
+  }
+  /// <name>.dbIdx (ids) / .dblas (lambda bytes) / .dbcodes / .dbcount (int per line), line-major
+  void writeDbToFile(const std::string& name) {
+    FAISS_THROW_IF_NOT_MSG(line_, "not a VLQ index");
+    std::ofstream fi((name + ".dbIdx").c_str(), std::ofstream::binary), fl((name + ".dblas").c_str(), std::ofstream::binary),
+        fc((name + ".dbcodes").c_str(), std::ofstream::binary), fn((name + ".dbcount").c_str(), std::ofstream::binary);
+    FAISS_THROW_IF_NOT_MSG(fi.good() && fl.good() && fc.good() && fn.good(), "cannot open db files for writing");
+    const int64_t nl = (int64_t)nlist_ * numedge_;
+    std::vector<int> counts(nl);
+    std::vector<uint8_t> c, l;
+    std::vector<int64_t> ids;
+    for (int64_t i = 0; i < nl; i++) {
+      int64_t len = 0;
+      VLQ_CHECK(vlq_line_list_length(line_, i, &len));
+      counts[i] = (int)len;
+      if (len == 0) continue;
+      c.resize((size_t)len * subQuantizers_); l.resize(len); ids.resize(len);
+      VLQ_CHECK(vlq_line_get_list(line_, i, c.data(), l.data(), ids.data()));
+      fi.write((const char*)ids.data(), len * sizeof(long));
+      fl.write((const char*)l.data(), len);
+      fc.write((const char*)c.data(), c.size());
+    }
+    fn.write((const char*)counts.data(), counts.size() * sizeof(int));
+  }
+  /// all lines, or only the list range of `rank` out of `pronum` processes: foreign lines stay
+  /// empty, exactly what the fork's per-rank loader does (gpu/GpuIndexIVFPQ.cu:2106-2163)
+  void readDbFromFile(const std::string& name, int pronum = 1, int rank = 0) {
+    FAISS_THROW_IF_NOT_MSG(line_, "not a VLQ index");
+    std::ifstream fi((name + ".dbIdx").c_str(), std::ifstream::binary), fl((name + ".dblas").c_str(), std::ifstream::binary),
+        fc((name + ".dbcodes").c_str(), std::ifstream::binary), fn((name + ".dbcount").c_str(), std::ifstream::binary);
+    FAISS_THROW_IF_NOT_MSG(fi.good() && fl.good() && fc.good() && fn.good(), "cannot open db files");
+    const int64_t nl = (int64_t)nlist_ * numedge_;
+    std::vector<int> counts(nl);
+    fn.read((char*)counts.data(), counts.size() * sizeof(int));
+    begin_ = (int)((int64_t)rank * nl / pronum);
+    end_ = (int)((int64_t)(rank + 1) * nl / pronum);
+    std::vector<int64_t> off(nl + 1, 0);
+    int64_t skip = 0, take = 0;
+    for (int64_t i = 0; i < nl; i++) {
+      const bool mine = i >= begin_ && i < end_;
+      off[i + 1] = off[i] + (mine ? counts[i] : 0);
+      if (i < begin_) skip += counts[i];
+      if (mine) take += counts[i];
+    }
+    std::vector<int64_t> ids(take);
+    std::vector<uint8_t> l(take), c((size_t)take * subQuantizers_);
+    fi.seekg(skip * (int64_t)sizeof(long)); fl.seekg(skip); fc.seekg(skip * subQuantizers_);
+    fi.read((char*)ids.data(), take * sizeof(long));
+    fl.read((char*)l.data(), take);
+    fc.read((char*)c.data(), c.size());
+    FAISS_THROW_IF_NOT_MSG(fi.good() && fl.good() && fc.good(), "db files too short");
+    VLQ_CHECK(vlq_line_set_lists(line_, c.data(), l.data(), ids.data(), off.data()));
+    ntotal = take;
+  }
 
  private:
   /// GpuIndexIVFPQ::train of the fork (gpu/GpuIndexIVFPQ.cu:1160-1178): coarse k-means,

@@ -119,6 +119,14 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
 int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe,
                             float* coarse_dis, int64_t* keys);
 
+/* Merge of per-shard results for indexes whose inverted lists are split over GPUs / ranks
+ * (GpuIndexIVFPQ::merge, gpu/GpuIndexIVFPQ.cu:1467-1591, used by gpu/test/deep1b16_query.cpp
+ * after the gather; IndexShards::search merge, MetaIndexes.cpp:486-557).  D_parts / I_parts
+ * are [nparts][nq][k] DEVICE buffers (e.g. the output of an all-gather); D / I [nq][k]
+ * device.  Ties go to the lower part, then the lower rank. */
+int vlq_merge_topk(int device, void* hip_stream, int64_t nq, int k, int nparts, const float* D_parts,
+                   const int64_t* I_parts, float* D, int64_t* I);
+
 /* Introspection for parity tests (host output buffers):
  *   query tables  = ProductQuantizer::compute_inner_prod_table /
  *                   compute_distance_table (ProductQuantizer.cpp:410-436): out[n][M][ksub]

@@ -106,6 +106,32 @@ int main() {
            v_ok, nq, (int)(nq * 0.3), vlqIndex.ntotal, vlqIndex.edgeInfo_[0], vlqIndex.edgeDistInfo_[0], vlqIndex.lambdaInfo_[0]);
     EXPECT(v_ok > nq * 0.3);
     EXPECT(vlqIndex.isVLQ() && vlqIndex.ntotal == (faiss::Index::idx_t)nb);
+    // the fork's raw files: a second index loaded from .ppqt/.db* answers identically, and
+    // two list-range shards (readDbFromFile(name, 2, r)) merged with merge() do too
+    vlqIndex.writeCodebookToFile("/tmp/vlq_test");
+    vlqIndex.writeDbToFile("/tmp/vlq_test");
+    std::vector<faiss::Index::idx_t> parts_n((size_t)2 * nq * k);
+    std::vector<float> parts_d((size_t)2 * nq * k);
+    for (int r = -1; r < 2; r++) {
+      faiss::gpu::GpuIndexIVFPQ re(&res, d, ncentroids, 16, 8, 8, 32, faiss::METRIC_L2, config);
+      re.readCodebookFromFile("/tmp/vlq_test");
+      if (r < 0) re.readDbFromFile("/tmp/vlq_test"); else re.readDbFromFile("/tmp/vlq_test", 2, r);
+      re.setNumProbes(5);
+      re.w1_ = 40;
+      std::vector<faiss::Index::idx_t> rn((size_t)k * nq);
+      std::vector<float> rd((size_t)k * nq);
+      re.search(nq, queries.data(), k, rd.data(), rn.data());
+      if (r < 0) { EXPECT(rn == vnns && rd == vdis); }
+      else {
+        std::copy(rn.begin(), rn.end(), parts_n.begin() + (size_t)r * nq * k);
+        std::copy(rd.begin(), rd.end(), parts_d.begin() + (size_t)r * nq * k);
+      }
+    }
+    std::vector<faiss::Index::idx_t> mn((size_t)k * nq);
+    std::vector<float> md((size_t)k * nq);
+    vlqIndex.merge(parts_n.data(), parts_d.data(), k, nq, 2, md.data(), mn.data());
+    EXPECT(md == vdis);
+    for (const char* ext : {".ppqt", ".dbIdx", ".dblas", ".dbcodes", ".dbcount"}) remove((std::string("/tmp/vlq_test") + ext).c_str());
     // returned distances omit |q|^2 (gpu/impl/Distance.cu:286-291): adding it back gives >= 0
     for (int q = 0; q < 10; q++) {
       double qn = 0;

@@ -187,3 +187,30 @@ def test_device_resident_buffers():
     Do, Io = ox.search(case.xq, case.nprobe, case.k, canonical=True)
     assert np.array_equal(bits(D.cpu().numpy()), bits(Do))
     assert np.array_equal(I.cpu().numpy(), Io)
+
+
+@pytest.mark.parametrize("k,nparts", [(10, 2), (100, 8), (300, 3)])
+def test_merge_topk(k, nparts):
+    """vlq_merge_topk (list-sharded mode): the k smallest over the shards' sorted rows,
+    ties to the lower shard; -1 / FLT_MAX padding never wins."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(k)
+    nq = 37
+    D = np.sort(rng.integers(0, 50, (nparts, nq, k)).astype(np.float32), axis=2)   # many ties
+    I = rng.integers(0, 10 ** 9, (nparts, nq, k)).astype(np.int64)
+    D[1, :, k // 2:] = np.finfo(np.float32).max
+    I[1, :, k // 2:] = -1
+    Dd, Id = torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda()
+    Do = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    Io = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    from vector_line_quantization_amd._lib import check, lib
+    check(lib().vlq_merge_topk(C.c_int(0), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_int64(nq),
+                               C.c_int(k), C.c_int(nparts), C.c_void_p(Dd.data_ptr()), C.c_void_p(Id.data_ptr()),
+                               C.c_void_p(Do.data_ptr()), C.c_void_p(Io.data_ptr())))
+    torch.cuda.synchronize()
+    allD = np.concatenate(list(D), axis=1)
+    allI = np.concatenate(list(I), axis=1)
+    order = np.argsort(np.where(allI < 0, np.inf, allD), axis=1, kind="stable")[:, :k]
+    assert np.array_equal(Do.cpu().numpy(), np.take_along_axis(allD, order, 1))
+    assert np.array_equal(Io.cpu().numpy(), np.take_along_axis(allI, order, 1))

@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vector_line_quantization_amd.sharded import merge_shard_results, shard_bounds, sharded_search
+from vector_line_quantization_amd.sharded import (list_range, list_sharded_search, merge_shard_results,
+                                                  shard_bounds, sharded_search)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -76,3 +77,51 @@ def test_merge_shard_results_matches_global_topk():
     order = np.argsort(allD, axis=1, kind="stable")[:, :k]
     assert np.array_equal(Dm.numpy(), np.take_along_axis(allD, order, 1))
     assert np.array_equal(Im.numpy(), np.take_along_axis(allI, order, 1))
+
+
+def _worker_lists(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from util import Case
+    case = Case("c1_small")
+    ox = case.oracle_index()
+    # this rank keeps only the lists of its range: all other lists become empty
+    lo, hi = list_range(case.nlist, world, rank)
+    off = ox.list_offsets
+    keep = np.zeros(ox.ids.shape[0], bool)
+    keep[off[lo]:off[hi]] = True
+    lens = np.diff(off)
+    lens[:lo] = 0
+    lens[hi:] = 0
+    new_off = np.zeros_like(off)
+    np.cumsum(lens, out=new_off[1:])
+    ox.set_lists(ox.codes[keep], ox.ids[keep], new_off)
+
+    def local_search(xs, nprobe, k):
+        D, I = ox.search(xs.numpy(), nprobe, k, canonical=True)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    D, I = list_sharded_search(local_search, torch.from_numpy(case.xq), case.nprobe, case.k)
+    np.save(os.path.join(out_dir, "LD%d.npy" % rank), D.numpy())
+    np.save(os.path.join(out_dir, "LI%d.npy" % rank), I.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_list_sharded_search_world2(tmp_path):
+    """List-range sharding + merge returns the distances of the unsharded index (labels
+    may permute inside exact-distance ties: the merge orders ties by rank)."""
+    from util import Case, assert_same_topk
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_lists, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    case = Case("c1_small")
+    Dref, Iref = case.oracle_index().search(case.xq, case.nprobe, case.k, canonical=True)
+    for r in range(world):
+        D = np.load(tmp_path / ("LD%d.npy" % r))
+        I = np.load(tmp_path / ("LI%d.npy" % r))
+        assert_same_topk(D, I, Dref, Iref, "list-sharded")

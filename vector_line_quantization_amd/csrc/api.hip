@@ -616,6 +616,20 @@ int vlq_ivfpq_profile_read(vlq_ivfpq_t h, double ms[3], int64_t* calls, int rese
     return VLQ_OK;
 }
 
+int vlq_merge_topk(int device, void* hip_stream, int64_t nq, int k, int nparts, const float* D_parts,
+                   const int64_t* I_parts, float* D, int64_t* I) {
+    if (nq < 0 || k < 1 || k > VLQ_MAX_K || nparts < 1) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (nq == 0) return VLQ_OK;
+    if (!D_parts || !I_parts || !D || !I) return fail(VLQ_ERR_INVALID, "null buffer");
+    if ((int64_t)nparts * k >= (int64_t(1) << 31)) return fail(VLQ_ERR_UNSUPPORTED, "nparts*k too large");
+    if (!is_device_ptr(D_parts) || !is_device_ptr(I_parts) || !is_device_ptr(D) || !is_device_ptr(I))
+        return fail(VLQ_ERR_INVALID, "vlq_merge_topk takes device buffers (the per-shard results were all-gathered on the device)");
+    HIP_TRY(hipSetDevice(device));
+    vlq::launch_merge_topk(D_parts, I_parts, nq, k, nparts, D, I, reinterpret_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
 int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes) {
     TRY(check_ready(h, false));
     if (n < 0 || (n > 0 && (!x || !assign || !codes))) return fail(VLQ_ERR_INVALID, "bad argument");

@@ -61,6 +61,10 @@ void launch_scan16(const ScanArgs& a, hipStream_t s);
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s);
 
+// merge of per-shard results [nparts][nq][k] into the global top-k (list-sharded multi-GPU mode)
+void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,
+                       int64_t* I, hipStream_t s);
+
 // out[i][0..dc) = x[i][col0 .. col0+dc)
 void launch_gather_cols(const float* x, int64_t n, int d, int col0, int dc, float* out, hipStream_t s);
 

@@ -758,6 +758,63 @@ void launch_scan(const ScanArgs& a, hipStream_t s) {
     else launch_scan_t<16, false>(a, nbuf, lut_region, smem, s);
 }
 
+// ---------------------------------------------------------------------------
+// merge of per-shard top-k lists (GpuIndexIVFPQ::merge / mergekernel,
+// gpu/GpuIndexIVFPQ.cu:1467-1591; IndexShards merge_tables, MetaIndexes.cpp:486-557):
+// parts are [nparts][nq][k]; one wave per query selects the k smallest
+// (distance, part*k + rank).
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ Dp,
+                                                         const int64_t* __restrict__ Ip, int64_t nq,
+                                                         int k, int nparts, float* __restrict__ D,
+                                                         int64_t* __restrict__ I) {
+    __shared__ u64 queue[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    WaveSelect<KPL> sel;
+    sel.init(k, queue[wave], lane);
+    const int num = nparts * k;
+    for (int i0 = 0; i0 < num; i0 += 64) {
+        const int i = i0 + lane;
+        bool valid = i < num;
+        float v = 0.f;
+        if (valid) {
+            const int64_t src = ((int64_t)(i / k) * nq + q) * k + (i % k);
+            v = Dp[src];
+            valid = Ip[src] >= 0;          // padding entries (-1 / FLT_MAX) never win
+        }
+        sel.offer(v, (uint32_t)i, valid);
+    }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e >= k) continue;
+        const u64 key = sel.best[r];
+        float dis = FLT_MAX_F;
+        int64_t id = -1;
+        if (key != kMaxKey) {
+            const int i = (int)(uint32_t)key;
+            const int64_t src = ((int64_t)(i / k) * nq + q) * k + (i % k);
+            dis = Dp[src];
+            id = Ip[src];
+        }
+        D[q * k + e] = dis;
+        I[q * k + e] = id;
+    }
+}
+
+void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,
+                       int64_t* I, hipStream_t s) {
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (k <= 64) hipLaunchKernelGGL(merge_topk_kernel<1>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
+    else if (k <= 256) hipLaunchKernelGGL(merge_topk_kernel<4>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
+    else hipLaunchKernelGGL(merge_topk_kernel<16>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ x, int64_t n, int d, int col0, int dc,
                                    float* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
