@@ -22,3 +22,11 @@ shared = [len(set(k2[i]) & set(k2[i + 1])) for i in range(0, len(k2) - 1, 2)]
 print("sorted by (top1,top2): %.2f" % np.mean(shared))
 u, c = np.unique(keys[:, 0], return_counts=True)
 print("distinct top-1 cells:", len(u), "queries in cells with >=2 queries: %.3f" % (c[c >= 2].sum() / len(keys)))
+os.makedirs("gpurun_out", exist_ok=True)
+np.save("gpurun_out/bench_keys.npy", keys.astype(np.int32))
+off = g.list_offsets() if hasattr(g, "list_offsets") else None
+if off is None:
+    lens = np.array([g.list_length(i) for i in range(args.nlist)], dtype=np.int64)
+else:
+    lens = np.diff(off)
+np.save("gpurun_out/bench_lens.npy", lens)

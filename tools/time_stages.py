@@ -28,7 +28,7 @@ p = g.profile_read()
 print("lib=%s coarse_ms=%.4f" % (os.environ.get("VLQ_LIB_PATH", "default"), p["coarse_ms"] / reps))
 
 # scan stage on a synthetic index with SIFT1M-like list sizes
-nb = 1000000
+nb = int(os.environ.get('NB', 1000000))
 lens = rng.multinomial(nb, rng.dirichlet(np.full(nlist, 1.2)))
 off = np.zeros(nlist + 1, np.int64); np.cumsum(lens, out=off[1:])
 g.set_lists(rng.integers(0, 256, (nb, M), dtype=np.uint8), np.arange(nb, dtype=np.int64), off)

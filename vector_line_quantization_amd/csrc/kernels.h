@@ -57,6 +57,11 @@ struct ScanArgs {
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
+// wave-autonomous variant (scan16w.hip): nw = 2 or 4 waves per workgroup
+void launch_scan16w(const ScanArgs& a, int nw, hipStream_t s);
+// two neighbouring queries per workgroup, shared lists scanned once (scan16p.hip); needs a.qorder
+bool scan16p_supports(const ScanArgs& a);
+void launch_scan16p(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s);

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     // ---- per-query set-up -------------------------------------------------------
     const bool badkey = probe_meta_fill(a, q, pm, t, NT);
     float4 m2t3[NI];
+#if defined(VLQ_ABLB) && (VLQ_ABLB & 2)
+    for (int i = 0; i < NI; i++) m2t3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
     load_query_table16<NI>(a, q, t, lane, wave, m2t3);
+#endif
     __syncthreads();
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
@@ -91,7 +95,11 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         }
         return p;
     };
+#if defined(VLQ_ABLB) && (VLQ_ABLB & 1)
+    int ik = np_eff;            // kernel experiments: no probe loop
+#else
     int ik = prefetch(0);
+#endif
     int buf = 0;
     uint64_t nscan = 0;
     while (ik < np_eff) {
