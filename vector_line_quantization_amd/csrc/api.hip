@@ -254,10 +254,15 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 tq.stop();
             }
             StageTimer tm(h, 2);       // exactly the scan kernel
-            static const char* variant = getenv("VLQ_SCAN16");   // kernel experiments only
-            if (variant && variant[0] == 'p' && a.qorder && vlq::scan16p_supports(a)) vlq::launch_scan16p(a, h->stream);
+#ifdef VLQ_EXPERIMENTS
+            // kernel experiments (make libvlq_exp.so): never in the product library
+            static const char* variant = getenv("VLQ_SCAN16");
+            if (variant && variant[0] == '2') vlq::launch_scan16v2(a, h->stream);
+            else if (variant && variant[0] == 'p' && a.qorder && vlq::scan16p_supports(a)) vlq::launch_scan16p(a, h->stream);
             else if (variant && variant[0] == 'w') vlq::launch_scan16w(a, variant[1] == '2' ? 2 : variant[1] == '1' ? 1 : 4, h->stream);
-            else vlq::launch_scan16(a, h->stream);
+            else
+#endif
+            vlq::launch_scan16(a, h->stream);
             tm.stop();
         } else {
             StageTimer tm(h, 2);

@@ -57,6 +57,8 @@ struct ScanArgs {
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
+// second generation: whole-probe prefetch, scalar list bases (scan16v2.hip)
+void launch_scan16v2(const ScanArgs& a, hipStream_t s);
 // wave-autonomous variant (scan16w.hip): nw = 2 or 4 waves per workgroup
 void launch_scan16w(const ScanArgs& a, int nw, hipStream_t s);
 // two neighbouring queries per workgroup, shared lists scanned once (scan16p.hip); needs a.qorder
