@@ -133,6 +133,47 @@ def test_encode_and_add(case):
             assert np.array_equal(c, case["codes"][off[i]:off[i + 1]])
 
 
+@pytest.mark.parametrize("name", ["c1_small", "deep_like_dsub6", "imi_sse_tables"])
+def test_add_in_batches_appends_on_device(name):
+    """add() in uneven batches (device-side append: in-place when the slack suffices, relayout
+    with 25 % slack otherwise) == one add() == the reference's lists, incl. order inside a list
+    (IndexIVFPQ.cpp:236-248); searches before, between and after see exactly the stored vectors."""
+    case = Case(name)
+    g1 = gpu_index(case, with_lists=False)
+    g1.add(case.xb, case.xids)
+    g = gpu_index(case, with_lists=False)
+    cuts = [0, 1, 2, 700, 701, 1900, len(case.xb)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g.add(case.xb[a:b], None if case.xids is None else case.xids[a:b])
+        assert g.ntotal == b
+        if b == 701:       # a search in the middle of the build only sees the first 701 vectors
+            D, I = g.search(case.xq[:8], case.nprobe, case.k)
+            seen = set(range(701)) if case.xids is None else set(case.xids[:701].tolist())
+            assert set(I[I >= 0].tolist()) <= seen
+    for i in range(case.nlist):
+        c, ids = g.get_list(i)
+        c1, ids1 = g1.get_list(i)
+        assert np.array_equal(ids, ids1) and np.array_equal(c, c1)
+    D, I = g.search(case.xq, case.nprobe, case.k)
+    D1, I1 = g1.search(case.xq, case.nprobe, case.k)
+    assert np.array_equal(bits(D), bits(D1)) and np.array_equal(I, I1)
+    # packed lists loaded with set_lists and grown by add afterwards
+    g2 = gpu_index(case, with_lists=False)
+    g2.add(case.xb[:1900], None if case.xids is None else case.xids[:1900])
+    off = np.zeros(case.nlist + 1, np.int64)
+    cs, ids_ = [], []
+    for i in range(case.nlist):
+        c, ids = g2.get_list(i)
+        cs.append(c); ids_.append(ids); off[i + 1] = off[i] + len(ids)
+    g3 = gpu_index(case, with_lists=False)
+    g3.set_lists(np.concatenate(cs), np.concatenate(ids_), off)
+    g3.add(case.xb[1900:], None if case.xids is None else case.xids[1900:])
+    for i in range(case.nlist):
+        c, ids = g3.get_list(i)
+        c1, ids1 = g1.get_list(i)
+        assert np.array_equal(ids, ids1) and np.array_equal(c, c1)
+
+
 @pytest.mark.parametrize("k", [1, 64, 65, 256, 257, 1024])
 def test_large_k_and_k_boundaries(k):
     """k at the edges of the per-lane key counts of the wave select (1/4/16)."""

@@ -2,6 +2,7 @@
 // device buffers, workspace, paging of large query batches, host<->device staging.
 // No CPU compute path exists here: every search/add entry point launches kernels.
 #include "handle.h"
+#include "lists.h"
 
 namespace vlq_detail {
 
@@ -222,6 +223,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.codes = h->codes.as<uint8_t>();
         a.ids = h->ids.as<int64_t>();
         a.list_off = h->list_off.as<int64_t>();
+        a.list_len = h->list_len.as<int64_t>();
         a.term2 = table_mode == 1 ? h->term2.as<float>() : nullptr;
         a.qtab = (table_mode != 0 && !fused_tables) ? h->ws_qtab.as<float>() : nullptr;
         a.queries = xi;
@@ -334,13 +336,16 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
     h->h_list_off.assign((size_t)nlist + 1, 0);
+    h->h_list_len.assign((size_t)nlist, 0);
     int rc = h->stats.reserve(16);
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
+    if (rc == VLQ_OK) rc = h->list_len.reserve((size_t)nlist * 8);
     if (rc == VLQ_OK) rc = h->codes.reserve(16);
     if (rc == VLQ_OK) rc = h->ids.reserve(16);
     if (rc != VLQ_OK) { vlq_ivfpq_destroy(h); return rc; }
     (void)hipMemsetAsync(h->stats.p, 0, 16, h->stream);
     (void)hipMemsetAsync(h->list_off.p, 0, ((size_t)nlist + 1) * 8, h->stream);
+    (void)hipMemsetAsync(h->list_len.p, 0, (size_t)nlist * 8, h->stream);
     (void)hipStreamSynchronize(h->stream);
     h->have_lists = true;   // an empty index is searchable (all lists empty)
     *out = h;
@@ -354,7 +359,8 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
-                      &h->list_off, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
+                      &h->list_off, &h->list_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats, &h->imi_cent,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi};
@@ -470,9 +476,13 @@ int vlq_ivfpq_set_lists(vlq_ivfpq_t h, const uint8_t* codes, const int64_t* ids,
         HIP_TRY(hipMemcpyAsync(h->codes.p, codes, (size_t)ntotal * h->M, hipMemcpyDefault, h->stream));
         HIP_TRY(hipMemcpyAsync(h->ids.p, ids, (size_t)ntotal * 8, hipMemcpyDefault, h->stream));
     }
+    std::vector<int64_t> len((size_t)h->nlist);
+    for (int i = 0; i < h->nlist; i++) len[(size_t)i] = off[(size_t)i + 1] - off[(size_t)i];   // packed: capacity == length
     HIP_TRY(hipMemcpyAsync(h->list_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->list_len.p, len.data(), len.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->h_list_off = off;
+    h->h_list_len.swap(len);
     h->ntotal = ntotal;
     h->have_lists = true;
     return VLQ_OK;
@@ -483,7 +493,7 @@ int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h) { return h ? h->ntotal : -1; }
 int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len) {
     if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
     if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
-    *len = h->h_list_off[list_id + 1] - h->h_list_off[list_id];
+    *len = h->h_list_len[list_id];
     return VLQ_OK;
 }
 
@@ -491,7 +501,7 @@ int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* 
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
     TRY(set_dev(h));
-    const int64_t o = h->h_list_off[list_id], len = h->h_list_off[list_id + 1] - o;
+    const int64_t o = h->h_list_off[list_id], len = h->h_list_len[list_id];
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (len > 0 && codes_out)
         HIP_TRY(hipMemcpy(codes_out, h->codes.as<uint8_t>() + o * h->M, (size_t)len * h->M, hipMemcpyDeviceToHost));
@@ -638,6 +648,18 @@ int vlq_merge_topk(int device, void* hip_stream, int64_t nq, int k, int nparts, 
     return VLQ_OK;
 }
 
+// device pointers in and out: list assignment (quantizer->assign, IndexIVFPQ.cpp:205 = 1-NN
+// search) and PQ codes of the residuals
+static int encode_dev(vlq_ivfpq_t h, int64_t n, const float* xd, int64_t* ad, uint8_t* cd) {
+    TRY(h->ws_misc.reserve((size_t)n * 4));
+    TRY(coarse_dev(h, n, xd, 1, h->ws_misc.as<float>(), ad));
+    vlq::launch_residual_encode(xd, n, h->d, h->imi_nbits > 0 ? h->imi_cent.as<float>() : h->coarse.as<float>(),
+                                ad, h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub, cd, h->stream,
+                                h->imi_nbits);
+    HIP_TRY(hipGetLastError());
+    return VLQ_OK;
+}
+
 int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes) {
     TRY(check_ready(h, false));
     if (n < 0 || (n > 0 && (!x || !assign || !codes))) return fail(VLQ_ERR_INVALID, "bad argument");
@@ -649,14 +671,7 @@ int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, 
     bool copy_a, copy_c;
     TRY(stage_out(assign, (size_t)n * 8, h->ws_assign, &ad, &copy_a));
     TRY(stage_out(codes, (size_t)n * h->M, h->ws_codes, &cd, &copy_c));
-    TRY(h->ws_misc.reserve((size_t)n * 4));
-    // quantizer->assign (IndexIVFPQ.cpp:205) = 1-NN search
-    TRY(coarse_dev(h, n, (const float*)xd, 1, h->ws_misc.as<float>(), (int64_t*)ad));
-    vlq::launch_residual_encode((const float*)xd, n, h->d,
-                                h->imi_nbits > 0 ? h->imi_cent.as<float>() : h->coarse.as<float>(),
-                                (const int64_t*)ad, h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub,
-                                (uint8_t*)cd, h->stream, h->imi_nbits);
-    HIP_TRY(hipGetLastError());
+    TRY(encode_dev(h, n, (const float*)xd, (int64_t*)ad, (uint8_t*)cd));
     return finish_outputs(h, copy_a, assign, ad, (size_t)n * 8, copy_c, codes, cd, (size_t)n * h->M);
 }
 
@@ -665,57 +680,22 @@ int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids)
     if (n < 0 || (n > 0 && !x)) return fail(VLQ_ERR_INVALID, "bad argument");
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
-    // encode on the device
-    std::vector<int64_t> assign((size_t)n);
-    DevBuf new_codes;
-    TRY(new_codes.reserve((size_t)n * h->M));
-    int rc = vlq_ivfpq_encode(h, n, x, assign.data(), new_codes.as<uint8_t>());
-    if (rc != VLQ_OK) { new_codes.release(); return rc; }
-    // host side: stable placement (append in input order, IndexIVFPQ.cpp:236-248)
-    std::vector<int64_t> cnt((size_t)h->nlist, 0);
-    for (int64_t i = 0; i < n; i++) if (assign[i] >= 0) cnt[assign[i]]++;
-    std::vector<int64_t> new_off((size_t)h->nlist + 1, 0);
-    for (int i = 0; i < h->nlist; i++)
-        new_off[i + 1] = new_off[i] + (h->h_list_off[i + 1] - h->h_list_off[i]) + cnt[i];
-    const int64_t new_total = new_off[h->nlist];
-    std::vector<uint8_t> hc((size_t)new_total * h->M);
-    std::vector<int64_t> hi((size_t)new_total);
-    // old content
-    std::vector<uint8_t> oc((size_t)h->ntotal * h->M);
-    std::vector<int64_t> oi((size_t)h->ntotal);
-    std::vector<uint8_t> nc((size_t)n * h->M);
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->ntotal > 0) {
-        HIP_TRY(hipMemcpy(oc.data(), h->codes.p, oc.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(oi.data(), h->ids.p, oi.size() * 8, hipMemcpyDeviceToHost));
-    }
-    HIP_TRY(hipMemcpy(nc.data(), new_codes.p, nc.size(), hipMemcpyDeviceToHost));
-    new_codes.release();
-    std::vector<int64_t> ids_in;
-    if (xids) {
-        ids_in.resize((size_t)n);
-        HIP_TRY(hipMemcpy(ids_in.data(), xids, (size_t)n * 8, hipMemcpyDefault));
-    }
-    std::vector<int64_t> fill((size_t)h->nlist);
-    for (int i = 0; i < h->nlist; i++) {
-        const int64_t o = h->h_list_off[i], len = h->h_list_off[i + 1] - o;
-        if (len > 0) {
-            memcpy(&hc[(size_t)new_off[i] * h->M], &oc[(size_t)o * h->M], (size_t)len * h->M);
-            memcpy(&hi[(size_t)new_off[i]], &oi[(size_t)o], (size_t)len * 8);
-        }
-        fill[i] = new_off[i] + len;
-    }
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t key = assign[i];
-        if (key < 0) continue;                                  // IndexIVFPQ.cpp:238-243
-        const int64_t p = fill[key]++;
-        memcpy(&hc[(size_t)p * h->M], &nc[(size_t)i * h->M], (size_t)h->M);
-        hi[(size_t)p] = xids ? ids_in[(size_t)i] : h->ntotal + i;   // IndexIVFPQ.cpp:244
-    }
-    const int64_t ntotal_after = h->ntotal + n;                 // IndexIVFPQ.cpp:271
-    rc = vlq_ivfpq_set_lists(h, hc.data(), hi.data(), new_off.data());
-    if (rc != VLQ_OK) return rc;
-    h->ntotal = ntotal_after;
+    // encode and append on the device (IndexIVFPQ.cpp:192-272; gpu/impl/IVFPQ.cu:197-426,
+    // gpu/impl/InvertedListAppend.cu:122-247): nothing but the per-list counts visits the host
+    const void* xd;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    TRY(h->ws_assign.reserve((size_t)n * 8));
+    TRY(h->ws_codes.reserve((size_t)n * h->M));
+    TRY(encode_dev(h, n, (const float*)xd, h->ws_assign.as<int64_t>(), h->ws_codes.as<uint8_t>()));
+    const void* idd = nullptr;
+    if (xids) TRY(stage_in(h, xids, (size_t)n * 8, h->ws_keys_in, &idd));
+    vlq::ListStore ls;
+    ls.nlist = h->nlist; ls.code_size = h->M;
+    ls.codes = &h->codes; ls.ids = &h->ids; ls.off = &h->list_off; ls.len = &h->list_len;
+    ls.h_off = &h->h_list_off; ls.h_len = &h->h_list_len;
+    TRY(vlq::lists_append(ls, h->ws_append, n, h->ws_assign.as<int64_t>(), nullptr, h->ws_codes.as<uint8_t>(),
+                          nullptr, (const int64_t*)idd, h->ntotal, h->stream));
+    h->ntotal += n;                                             // IndexIVFPQ.cpp:271
     return VLQ_OK;
 }
 

@@ -74,6 +74,10 @@ inline bool is_device_ptr(const void* p) {
 }  // namespace vlq_detail
 using namespace vlq_detail;
 
+struct AppendWs {   // lists.h AppendWorkspace (kept opaque here: handle.h is included by lists.h)
+    DevBuf cnt, cstart, keys_in, keys_out, sort_tmp;
+};
+
 struct vlq_ivfpq_s {
     int device = 0, d = 0, nlist = 0, M = 0, nbits = 0, ksub = 0, dsub = 0;
     int by_residual = 1, use_precomputed_table = 1;
@@ -81,13 +85,15 @@ struct vlq_ivfpq_s {
     int64_t ntotal = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
 
-    DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off;
+    // inverted lists: list i at [list_off[i], list_off[i] + list_len[i]), capacity list_off[i+1] - list_off[i]
+    DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off, list_len;
     // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,
     // and the kc virtual full vectors whose term2 rows make table type 2
     int imi_nbits = 0;
     DevBuf imi_cent, imi_norm, imi_virtual, ws_imi;
     bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
-    std::vector<int64_t> h_list_off;
+    std::vector<int64_t> h_list_off, h_list_len;
+    AppendWs ws_append;
 
     // workspace
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,

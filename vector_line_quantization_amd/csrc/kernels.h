@@ -32,7 +32,8 @@ void launch_pq_tables(const float* x, int64_t nv, int d, const float* cent, int 
 struct ScanArgs {
     const uint8_t* codes;        // [ntotal][M] list-contiguous
     const int64_t* ids;          // [ntotal]
-    const int64_t* list_off;     // [nlist+1]
+    const int64_t* list_off;     // [nlist+1] list starts
+    const int64_t* list_len = nullptr;   // [nlist] lengths, or nullptr: packed lists (len = off[i+1] - off[i])
     const float* term2;          // [nlist][M*ksub]   (table mode 1) or nullptr
     const float* qtab;           // [nq][M*ksub] per-query table (ip table or distance table)
     const float* queries;        // [nq][d]          (table mode 0 only)

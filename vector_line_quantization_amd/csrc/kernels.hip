@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a, int nbuf, int lut
         int64_t len = 0, off = 0;
         if (key >= a.nlist) badkey = true;                  // IndexIVFPQ.cpp:1008-1011
         const bool live = key >= 0 && key < a.nlist;
-        if (live) { off = a.list_off[key]; len = a.list_off[key + 1] - off; }
+        if (live) { off = a.list_off[key]; len = a.list_len ? a.list_len[key] : a.list_off[key + 1] - off; }
         float dis0 = 0.f;
 
         if (len > 0) {

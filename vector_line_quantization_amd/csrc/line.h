@@ -20,7 +20,8 @@ struct LineScanArgs {
     const uint8_t* codes;        // [ntotal][M] line-contiguous
     const uint8_t* lambdas;      // [ntotal]
     const int64_t* ids;          // [ntotal]
-    const int64_t* line_off;     // [nlist*nedge + 1]
+    const int64_t* line_off;     // [nlist*nedge + 1] line starts
+    const int64_t* line_len = nullptr;   // [nlist*nedge] lengths, or nullptr: packed (lists.h)
     const float* term2;          // [nlist][M*ksub]
     const float* qtab;           // [nq][M*ksub]  <q_m, cent_mj>
     const int32_t* edge_info;    // [nlist*nedge]

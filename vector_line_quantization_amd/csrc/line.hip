@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_
         if (t == 0) cum[w] = pos0;
         if (line < 0) continue;
         const int64_t off = a.line_off[line];
-        int64_t len = a.line_off[line + 1] - off;
+        int64_t len = a.line_len ? a.line_len[line] : a.line_off[line + 1] - off;
         if (len > a.max_line_codes) len = a.max_line_codes;
         if (len <= 0) continue;
         const int c = line / a.nedge;

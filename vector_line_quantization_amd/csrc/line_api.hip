@@ -3,15 +3,17 @@
 // (an embedded vlq_ivfpq handle), the line-specific stages are line.hip.
 #include "../../include/vlq_line.h"
 #include "handle.h"
+#include "lists.h"
 #include "line.h"
 
 struct vlq_line_s {
     vlq_ivfpq_t base = nullptr;          // coarse centroids, PQ, term2, workspace, stream
     int nedge = 0, nlambda = 0;
     int64_t nlines = 0, ntotal = 0, ntotal_added = 0;
-    DevBuf edge_info, edge_dist, lambda_info, codes, lambdas, ids, line_off;
+    DevBuf edge_info, edge_dist, lambda_info, codes, lambdas, ids, line_off, line_len;   // lists.h layout
     bool have_graph = false, have_lambda = false;
-    std::vector<int64_t> h_line_off;
+    std::vector<int64_t> h_line_off, h_line_len;
+    AppendWs ws_append;
     std::vector<float> h_lambda;
     DevBuf ws_near, ws_line, ws_lamf, ws_lamb, ws_res, ws_codes, ws_sel_line, ws_sel_b2, ws_sel_g,
         ws_x, ws_D, ws_I, ws_keys, ws_cdis, stats;
@@ -87,13 +89,16 @@ int vlq_line_create(vlq_line_t* out, int device, int d, int nlist, int M, int nb
     if (rc != VLQ_OK) { delete h; return rc; }
     h->nedge = nedge; h->nlambda = nlambda; h->nlines = (int64_t)nlist * nedge;
     h->h_line_off.assign((size_t)h->nlines + 1, 0);
+    h->h_line_len.assign((size_t)h->nlines, 0);
     rc = h->line_off.reserve(((size_t)h->nlines + 1) * 8);
+    if (rc == VLQ_OK) rc = h->line_len.reserve((size_t)h->nlines * 8);
     if (rc == VLQ_OK) rc = h->stats.reserve(16);
     if (rc == VLQ_OK) rc = h->codes.reserve(16);
     if (rc == VLQ_OK) rc = h->lambdas.reserve(16);
     if (rc == VLQ_OK) rc = h->ids.reserve(16);
     if (rc != VLQ_OK) { vlq_line_destroy(h); return rc; }
     (void)hipMemsetAsync(h->line_off.p, 0, ((size_t)h->nlines + 1) * 8, h->base->stream);
+    (void)hipMemsetAsync(h->line_len.p, 0, (size_t)h->nlines * 8, h->base->stream);
     (void)hipMemsetAsync(h->stats.p, 0, 16, h->base->stream);
     (void)hipStreamSynchronize(h->base->stream);
     *out = h;
@@ -104,7 +109,8 @@ void vlq_line_destroy(vlq_line_t h) {
     if (!h) return;
     if (h->base) { (void)hipSetDevice(h->base->device); (void)hipStreamSynchronize(h->base->stream); }
     DevBuf* bufs[] = {&h->edge_info, &h->edge_dist, &h->lambda_info, &h->codes, &h->lambdas, &h->ids,
-                      &h->line_off, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
+                      &h->line_off, &h->line_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
                       &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_x, &h->ws_D,
                       &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats};
     for (auto b : bufs) b->release();
@@ -263,9 +269,13 @@ int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambda
         HIP_TRY(hipMemcpyAsync(h->lambdas.p, lambdas, (size_t)nt, hipMemcpyDefault, b->stream));
         HIP_TRY(hipMemcpyAsync(h->ids.p, ids, (size_t)nt * 8, hipMemcpyDefault, b->stream));
     }
+    std::vector<int64_t> len((size_t)h->nlines);
+    for (int64_t i = 0; i < h->nlines; i++) len[(size_t)i] = off[(size_t)i + 1] - off[(size_t)i];
     HIP_TRY(hipMemcpyAsync(h->line_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(h->line_len.p, len.data(), len.size() * 8, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     h->h_line_off.swap(off);
+    h->h_line_len.swap(len);
     h->ntotal = nt;
     return VLQ_OK;
 }
@@ -276,44 +286,22 @@ int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids) {
     if (n == 0) return VLQ_OK;
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
-    std::vector<int32_t> line((size_t)n);
-    std::vector<uint8_t> lam((size_t)n), nc((size_t)n * b->M);
-    TRY(vlq_line_encode(h, n, x, line.data(), lam.data(), nc.data()));
-    std::vector<int64_t> ids_in;
-    if (xids) { ids_in.resize((size_t)n); HIP_TRY(hipMemcpy(ids_in.data(), xids, (size_t)n * 8, hipMemcpyDefault)); }
-    // host-side stable append per line (the reference also keeps the codes on the host
-    // until they are written out, gpu/GpuIndexIVFPQ.cu:852-857)
-    std::vector<uint8_t> oc((size_t)h->ntotal * b->M), ol((size_t)h->ntotal);
-    std::vector<int64_t> oi((size_t)h->ntotal);
-    if (h->ntotal > 0) {
-        HIP_TRY(hipMemcpy(oc.data(), h->codes.p, oc.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ol.data(), h->lambdas.p, ol.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(oi.data(), h->ids.p, oi.size() * 8, hipMemcpyDeviceToHost));
-    }
-    std::vector<int64_t> new_off((size_t)h->nlines + 1, 0);
-    for (int64_t i = 0; i < n; i++) if (line[i] >= 0) new_off[(size_t)line[i] + 1]++;
-    for (int64_t l = 0; l < h->nlines; l++)
-        new_off[l + 1] += new_off[l] + (h->h_line_off[l + 1] - h->h_line_off[l]);
-    const int64_t nt = new_off[h->nlines];
-    std::vector<uint8_t> hc((size_t)nt * b->M), hl((size_t)nt);
-    std::vector<int64_t> hi((size_t)nt), fill((size_t)h->nlines);
-    for (int64_t l = 0; l < h->nlines; l++) {
-        const int64_t o = h->h_line_off[l], len = h->h_line_off[l + 1] - o;
-        if (len > 0) {
-            memcpy(&hc[(size_t)new_off[l] * b->M], &oc[(size_t)o * b->M], (size_t)len * b->M);
-            memcpy(&hl[(size_t)new_off[l]], &ol[(size_t)o], (size_t)len);
-            memcpy(&hi[(size_t)new_off[l]], &oi[(size_t)o], (size_t)len * 8);
-        }
-        fill[l] = new_off[l] + len;
-    }
-    for (int64_t i = 0; i < n; i++) {
-        if (line[i] < 0) continue;
-        const int64_t p = fill[line[i]]++;
-        memcpy(&hc[(size_t)p * b->M], &nc[(size_t)i * b->M], (size_t)b->M);
-        hl[(size_t)p] = lam[(size_t)i];
-        hi[(size_t)p] = xids ? ids_in[(size_t)i] : h->ntotal_added + i;
-    }
-    TRY(vlq_line_set_lists(h, hc.data(), hl.data(), hi.data(), new_off.data()));
+    // assign + encode + append on the device; the reference keeps the encoded batch on the host
+    // until it is written out (gpu/GpuIndexIVFPQ.cu:852-857)
+    const void* xd;
+    TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
+    TRY(encode_dev(h, n, (const float*)xd));
+    const void* idd = nullptr;
+    if (xids) TRY(stage_in(b, xids, (size_t)n * 8, h->ws_keys, &idd));
+    vlq::ListStore ls;
+    ls.nlist = h->nlines; ls.code_size = b->M;
+    ls.codes = &h->codes; ls.lambdas = &h->lambdas; ls.ids = &h->ids; ls.off = &h->line_off; ls.len = &h->line_len;
+    ls.h_off = &h->h_line_off; ls.h_len = &h->h_line_len;
+    TRY(vlq::lists_append(ls, h->ws_append, n, nullptr, h->ws_line.as<int32_t>(), h->ws_codes.as<uint8_t>(),
+                          h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream));
+    int64_t stored = 0;
+    for (int64_t v : h->h_line_len) stored += v;
+    h->ntotal = stored;
     h->ntotal_added += n;
     return VLQ_OK;
 }
@@ -323,7 +311,7 @@ int64_t vlq_line_ntotal(vlq_line_t h) { return h ? h->ntotal : -1; }
 int vlq_line_list_length(vlq_line_t h, int64_t line, int64_t* len) {
     if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
     if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
-    *len = h->h_line_off[line + 1] - h->h_line_off[line];
+    *len = h->h_line_len[line];
     return VLQ_OK;
 }
 
@@ -332,7 +320,7 @@ int vlq_line_get_list(vlq_line_t h, int64_t line, uint8_t* codes_out, uint8_t* l
     if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
-    const int64_t o = h->h_line_off[line], len = h->h_line_off[line + 1] - o;
+    const int64_t o = h->h_line_off[line], len = h->h_line_len[line];
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (len > 0 && codes_out) HIP_TRY(hipMemcpy(codes_out, h->codes.as<uint8_t>() + o * b->M, (size_t)len * b->M, hipMemcpyDeviceToHost));
     if (len > 0 && lambdas_out) HIP_TRY(hipMemcpy(lambdas_out, h->lambdas.as<uint8_t>() + o, (size_t)len, hipMemcpyDeviceToHost));
@@ -384,7 +372,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         // 4. scan + top-k
         vlq::LineScanArgs a;
         a.codes = h->codes.as<uint8_t>(); a.lambdas = h->lambdas.as<uint8_t>(); a.ids = h->ids.as<int64_t>();
-        a.line_off = h->line_off.as<int64_t>(); a.term2 = b->term2.as<float>(); a.qtab = b->ws_qtab.as<float>();
+        a.line_off = h->line_off.as<int64_t>(); a.line_len = h->line_len.as<int64_t>(); a.term2 = b->term2.as<float>(); a.qtab = b->ws_qtab.as<float>();
         a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
         a.lambda_info = h->lambda_info.as<float>();
         a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();

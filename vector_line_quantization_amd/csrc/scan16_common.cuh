@@ -174,7 +174,7 @@ __device__ __forceinline__ bool probe_meta_fill(const ScanArgs& a, int64_t q, Pr
         if (key >= a.nlist) badkey = true;                 // IndexIVFPQ.cpp:1008-1011
         const bool live = key >= 0 && key < a.nlist;
         int64_t off = 0, len = 0;
-        if (live) { off = a.list_off[key]; len = a.list_off[key + 1] - off; }
+        if (live) { off = a.list_off[key]; len = a.list_len ? a.list_len[key] : a.list_off[key + 1] - off; }
         pm.poff[p] = off;
         pm.plen[p] = (uint32_t)len;
         pm.pkey[p] = (live && len > 0) ? (int32_t)key : -1;   // empty lists are skipped (:1016)
