@@ -210,6 +210,9 @@ int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe
             }
             const int nw = std::min<int>(w1, (int)lines.size());
             std::partial_sort(lines.begin(), lines.begin() + nw, lines.end(), vless);
+            // the kept lines are walked in candidate order (probe rank, edge): lines that share
+            // their anchor centroid are neighbours, and scan positions (ties) follow this order
+            std::sort(lines.begin(), lines.begin() + nw, [](const VCand& a, const VCand& b) { return a.pos < b.pos; });
             for (int m = 0; m < ix->M; m++)
                 for (int j = 0; j < ix->ksub; j++)
                     t3[m * ix->ksub + j] = -2.0f * orc_fvec_inner_product(

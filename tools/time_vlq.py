@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""VLQ (line quantization) search timing on synthetic data (kernel experiments).
+   python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import vector_line_quantization_amd as vlq
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+E = lambda k, v: int(os.environ.get(k, v))
+d, nlist, nedge, M = E("D", 96), E("NLIST", 4096), E("NEDGE", 16), 16
+nb, nprobe, w1, k = E("NB", 4000000), E("NPROBE", 64), E("W1", 1024), E("K", 128)
+rng = np.random.default_rng(0)
+g = vlq.GpuVLQ(d, nlist, M, 8, nedge, 256)
+cent = rng.random((nlist, d), dtype=np.float32)
+g.set_coarse_centroids(cent)
+g.build_graph()
+g.set_lambda_codebook(np.linspace(-0.2, 1.2, 256).astype(np.float32))
+g.set_pq_centroids((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2)
+t0 = time.time()
+gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+step = 1000000
+for i in range(0, nb, step):
+    n = min(step, nb - i)
+    pick = torch.randint(0, nlist, (n,), device="cuda", generator=gen)
+    x = torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((n, d), device="cuda", generator=gen)
+    g.add(x.contiguous())
+torch.cuda.synchronize()
+print("added %d vectors in %.1f s (%d lines, %.1f per line)" % (nb, time.time() - t0, nlist * nedge, nb / (nlist * nedge)), flush=True)
+pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
+xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
+D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+for _ in range(2):
+    g.search(xq, nprobe, w1, k, D=D, I=I)
+torch.cuda.synchronize()
+g.stats(reset=True)
+t0 = time.time()
+for _ in range(reps):
+    g.search(xq, nprobe, w1, k, D=D, I=I)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / reps
+ncode = g.stats() / reps
+print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s (17 B/code)" % (
+    dt * 1e3, nq, nq / dt, ncode / nq, ncode * 17 / dt / 1e9))

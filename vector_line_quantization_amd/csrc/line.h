@@ -12,9 +12,23 @@ void launch_lambda_quantize(const float* lambdaf, int64_t n, const float* lambda
 void launch_line_residuals(const float* x, int64_t n, int d, const float* coarse, const int32_t* edge_info,
                            int nedge, const int32_t* line_id, const uint8_t* lambda,
                            const float* lambda_info, float* res, hipStream_t s);
+// one selected, non-empty line as the 16-byte scan kernel reads it (32 bytes = two 16-byte loads)
+struct LineMeta {
+    int64_t off;      // first code of the line
+    int32_t len;      // codes scanned (capped at max_line_codes)
+    int32_t line;     // line id = c * nedge + e
+    int32_t s;        // far-end centroid
+    float c2;         // |s - c|^2
+    float b2;         // coarse value of the anchor c
+    float g;          // v[s] - v[c]
+};
+
+// sel_meta / sel_cnt (optional): compact LineMeta records [nq][w1] + their count per query
 void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,
                         const int32_t* edge_info, const float* edge_dist, int nedge, int w1,
-                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s);
+                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s,
+                        const int64_t* line_off = nullptr, const int64_t* line_len = nullptr,
+                        int max_line_codes = 0, LineMeta* sel_meta = nullptr, int32_t* sel_cnt = nullptr);
 
 struct LineScanArgs {
     const uint8_t* codes;        // [ntotal][M] line-contiguous
@@ -30,6 +44,8 @@ struct LineScanArgs {
     const int32_t* sel_line;     // [nq][w1]
     const float* sel_b2;         // [nq][w1]
     const float* sel_g;          // [nq][w1]
+    const LineMeta* sel_meta = nullptr;   // [nq][w1] compact records (16-byte scan)
+    const int32_t* sel_cnt = nullptr;     // [nq]
     float* D;
     int64_t* I;
     unsigned long long* ncode;

@@ -140,7 +140,9 @@ template <int KPL>
 __global__ __launch_bounds__(256) void line_select_kernel(
     const float* __restrict__ dist, int64_t nq, int nlist, const int64_t* __restrict__ keys,
     int nprobe, const int32_t* __restrict__ edge_info, const float* __restrict__ edge_dist, int nedge,
-    int w1, int32_t* __restrict__ sel_line, float* __restrict__ sel_b2, float* __restrict__ sel_g) {
+    int w1, int32_t* __restrict__ sel_line, float* __restrict__ sel_b2, float* __restrict__ sel_g,
+    const int64_t* __restrict__ line_off, const int64_t* __restrict__ line_len, int max_line_codes,
+    LineMeta* __restrict__ sel_meta, int32_t* __restrict__ sel_cnt) {
     __shared__ u64 queue[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -170,11 +172,22 @@ __global__ __launch_bounds__(256) void line_select_kernel(
         sel.offer(key, (uint32_t)i, valid);
     }
     sel.flush();
+    // the w1 winners, re-sorted by candidate index (probe rank, edge): lines sharing an anchor
+    // centroid become neighbours, so the scan builds the anchor's table once per group
+    WaveSelect<KPL> ord;
+    ord.init(w1, queue[wave], lane);
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const u64 k64 = sel.best[r];
+        const bool win = k64 != kMaxKey && r * 64 + lane < w1;
+        ord.offer_key((u64)(uint32_t)k64, win);
+    }
+    ord.flush();
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const int w = r * 64 + lane;
         if (w >= w1) continue;
-        const u64 k64 = sel.best[r];
+        const u64 k64 = ord.best[r];
         int32_t line = -1;
         float b2 = 0.f, g = 0.f;
         if (k64 != kMaxKey) {
@@ -190,19 +203,267 @@ __global__ __launch_bounds__(256) void line_select_kernel(
         sel_b2[q * w1 + w] = b2;
         sel_g[q * w1 + w] = g;
     }
+    if (!sel_meta) return;
+    // compact per-line records for the 16-byte scan: non-empty lines only, same order
+    int nkept = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int w = r * 64 + lane;
+        const u64 k64 = ord.best[r];
+        LineMeta m;
+        m.len = 0;
+        if (w < w1 && k64 != kMaxKey) {
+            const int i = (int)(uint32_t)k64;
+            const int64_t c = kq[i / nedge];
+            const int e = i % nedge;
+            const int64_t line = c * nedge + e;
+            m.off = line_off[line];
+            int64_t len = line_len ? line_len[line] : line_off[line + 1] - m.off;
+            if (len > max_line_codes) len = max_line_codes;
+            m.len = (int32_t)len;
+            m.line = (int32_t)line;
+            m.s = edge_info[line];
+            m.c2 = edge_dist[line];
+            m.b2 = row[c];
+            m.g = __fsub_rn(row[m.s], m.b2);
+        }
+        const bool keep = m.len > 0;
+        const u64 mask = __ballot(keep);
+        if (keep) sel_meta[q * w1 + nkept + __popcll(mask & ((1ull << lane) - 1ull))] = m;
+        nkept += __popcll(mask);
+    }
+    if (lane == 0) sel_cnt[q] = nkept;
 }
 
 void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,
                         const int32_t* edge_info, const float* edge_dist, int nedge, int w1,
-                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s) {
+                        int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s,
+                        const int64_t* line_off, const int64_t* line_len, int max_line_codes,
+                        LineMeta* sel_meta, int32_t* sel_cnt) {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 3) / 4)), block(256);
 #define VLQ_LS(K) hipLaunchKernelGGL(line_select_kernel<K>, grid, block, 0, s, dist, nq, nlist, keys, nprobe, \
-                                     edge_info, edge_dist, nedge, w1, sel_line, sel_b2, sel_g)
+                                     edge_info, edge_dist, nedge, w1, sel_line, sel_b2, sel_g, line_off,      \
+                                     line_len, max_line_codes, sel_meta, sel_cnt)
     if (w1 <= 64) VLQ_LS(1);
     else if (w1 <= 256) VLQ_LS(4);
     else VLQ_LS(16);
 #undef VLQ_LS
+}
+
+// Two LUTs, one address: T23 at LDS byte 0, T4 at byte 16384 (the kernel's dynamic LDS starts at
+// LDS address 0: no static LDS).  One SDWA op extracts a code byte and scales it by 4; the T4
+// read takes its own register, the T23 read lands in the address register.
+#define VLQ_L16_LO(W0, W1)                                                                      \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %8, %0 offset:16384\n\t" \
+        "ds_read_b32 %0, %0 offset:0\n\t" \
+        "ds_read_b32 %9, %1 offset:17408\n\t" \
+        "ds_read_b32 %1, %1 offset:1024\n\t" \
+        "ds_read_b32 %10, %2 offset:18432\n\t" \
+        "ds_read_b32 %2, %2 offset:2048\n\t" \
+        "ds_read_b32 %11, %3 offset:19456\n\t" \
+        "ds_read_b32 %3, %3 offset:3072\n\t" \
+        "ds_read_b32 %12, %4 offset:20480\n\t" \
+        "ds_read_b32 %4, %4 offset:4096\n\t" \
+        "ds_read_b32 %13, %5 offset:21504\n\t" \
+        "ds_read_b32 %5, %5 offset:5120\n\t" \
+        "ds_read_b32 %14, %6 offset:22528\n\t" \
+        "ds_read_b32 %6, %6 offset:6144\n\t" \
+        "ds_read_b32 %15, %7 offset:23552\n\t" \
+        "ds_read_b32 %7, %7 offset:7168\n\t" \
+        "s_waitcnt lgkmcnt(0)"                                                                                 \
+        : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]), "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two)                                                       \
+        : "memory")
+#define VLQ_L16_HI(W0, W1)                                                                      \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %8, %0 offset:24576\n\t" \
+        "ds_read_b32 %0, %0 offset:8192\n\t" \
+        "ds_read_b32 %9, %1 offset:25600\n\t" \
+        "ds_read_b32 %1, %1 offset:9216\n\t" \
+        "ds_read_b32 %10, %2 offset:26624\n\t" \
+        "ds_read_b32 %2, %2 offset:10240\n\t" \
+        "ds_read_b32 %11, %3 offset:27648\n\t" \
+        "ds_read_b32 %3, %3 offset:11264\n\t" \
+        "ds_read_b32 %12, %4 offset:28672\n\t" \
+        "ds_read_b32 %4, %4 offset:12288\n\t" \
+        "ds_read_b32 %13, %5 offset:29696\n\t" \
+        "ds_read_b32 %5, %5 offset:13312\n\t" \
+        "ds_read_b32 %14, %6 offset:30720\n\t" \
+        "ds_read_b32 %6, %6 offset:14336\n\t" \
+        "ds_read_b32 %15, %7 offset:31744\n\t" \
+        "ds_read_b32 %7, %7 offset:15360\n\t" \
+        "s_waitcnt lgkmcnt(0)"                                                                                 \
+        : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]), "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two)                                                       \
+        : "memory")
+
+// line scan specialised for 16-byte codes (M = 16, ksub = 256): same arithmetic as
+// line_scan_kernel below, organised like the IVFPQ scan16 kernel --
+//   * the selected lines arrive grouped by anchor centroid and without empty lines
+//     (LineMeta, written by line_select_kernel): T23 = term2[c] - 2<q, .> is rebuilt only when
+//     the anchor changes, the anchor's term2 row stays in registers, and a line costs one
+//     16 KB row read (term2[s]) and one 16 KB LDS table (T4 = term2[s] - term2[c]) instead of two;
+//   * the next line's row, its first code chunk and lambda bytes are requested before the
+//     current line is scanned; per-query -2<q, cent> (16 entries per thread) lives in registers;
+//   * one SDWA op per code byte serves both table lookups.
+template <int KPL>
+__global__ __launch_bounds__(256) void line16_scan_kernel(LineScanArgs a, int queue_off) {
+    constexpr int E = 4096, NT = 256, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* t23 = reinterpret_cast<float*>(smraw);                    // [E] at LDS byte 0
+    float* t4 = t23 + E;                                             // [E] at LDS byte 16384
+    float* lamtab = t4 + E;                                          // [256]
+    u64* queue = reinterpret_cast<u64*>(smraw + queue_off);          // [4][64]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t two = 2;
+    asm volatile("" : "+v"(two));
+    const int64_t q = blockIdx.x;
+    const int cnt = a.sel_cnt[q];
+    const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);
+
+    float4 m2q[NI];                       // -2 <q_m, cent_mj>, entries 4*(i*256+t) .. +3
+    {
+        const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const float4 v = qt[i * NT + t];
+            m2q[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z), __fmul_rn(-2.f, v.w));
+        }
+    }
+    lamtab[t] = a.lambda_info[t];         // padded to 256 entries by the host
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    float4 t2c[NI], ts[NI];
+    uint4 c0 = make_uint4(0, 0, 0, 0);
+    uint32_t l0 = 0;
+    auto prefetch = [&](const uint4 m0, const uint4 m1) __attribute__((always_inline)) {
+        const int64_t off = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+        const uint32_t len = m0.z;
+        const int32_t s = (int32_t)m1.x;
+        const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)s * E);
+#pragma unroll
+        for (int i = 0; i < NI; i++) ts[i] = src[i * NT + t];
+        const uint32_t j = min((uint32_t)t, len - 1);
+        c0 = reinterpret_cast<const uint4*>(a.codes)[off + j];
+        l0 = a.lambdas[off + j];
+    };
+    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, mb0 = ma0, mb1 = ma0;
+    if (cnt > 0) {
+        ma0 = mq[0]; ma1 = mq[1];
+        const int w1c = min(1, cnt - 1);
+        mb0 = mq[2 * w1c]; mb1 = mq[2 * w1c + 1];
+        prefetch(ma0, ma1);
+    }
+    int cprev = -1;
+    uint32_t pos0 = 0;
+    for (int w = 0; w < cnt; w++) {
+        const int64_t off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane(ma0.y) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane(ma0.x));
+        const uint32_t len = __builtin_amdgcn_readfirstlane(ma0.z);
+        const int line = __builtin_amdgcn_readfirstlane(ma0.w);
+        const float c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.y));
+        const float b2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.z));
+        const float g = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.w));
+        const int c = line / a.nedge;
+        if (t == 0) cum[w] = pos0;
+        __syncthreads();                         // previous line fully scanned
+        if (c != cprev) {                        // new anchor: its row into registers, T23 into LDS
+            const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)c * E);
+#pragma unroll
+            for (int i = 0; i < NI; i++) t2c[i] = src[i * NT + t];
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                float4 v;
+                v.x = __fadd_rn(t2c[i].x, m2q[i].x); v.y = __fadd_rn(t2c[i].y, m2q[i].y);
+                v.z = __fadd_rn(t2c[i].z, m2q[i].z); v.w = __fadd_rn(t2c[i].w, m2q[i].w);
+                reinterpret_cast<float4*>(t23)[i * NT + t] = v;
+            }
+            cprev = c;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            float4 v;
+            v.x = __fsub_rn(ts[i].x, t2c[i].x); v.y = __fsub_rn(ts[i].y, t2c[i].y);
+            v.z = __fsub_rn(ts[i].z, t2c[i].z); v.w = __fsub_rn(ts[i].w, t2c[i].w);
+            reinterpret_cast<float4*>(t4)[i * NT + t] = v;
+        }
+        uint4 cc = c0;
+        uint32_t lb = l0;
+        ma0 = mb0; ma1 = mb1;
+        if (w + 1 < cnt) {
+            prefetch(ma0, ma1);
+            const int w2 = min(w + 2, cnt - 1);
+            mb0 = mq[2 * w2]; mb1 = mq[2 * w2 + 1];
+        }
+        __syncthreads();
+        const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
+        const uint8_t* lp = a.lambdas + off;
+        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
+            const uint32_t j = j0 + lane;
+            const uint32_t jn = min(j + NT, len - 1);
+            const uint4 cn = cp[jn];
+            const uint32_t ln = lp[jn];
+            const float l = lamtab[lb];
+            float s23 = 0.f, s4 = 0.f;
+            {
+                float va[8], vb[8];
+                VLQ_L16_LO(cc.x, cc.y);
+#pragma unroll
+                for (int m = 0; m < 8; m++) { s23 = __fadd_rn(s23, va[m]); s4 = __fadd_rn(s4, vb[m]); }
+            }
+            {
+                float va[8], vb[8];
+                VLQ_L16_HI(cc.z, cc.w);
+#pragma unroll
+                for (int m = 0; m < 8; m++) { s23 = __fadd_rn(s23, va[m]); s4 = __fadd_rn(s4, vb[m]); }
+            }
+            const float head = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)),
+                                         __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+            const float dist = __fadd_rn(__fadd_rn(head, s23), __fmul_rn(l, s4));
+            sel.offer(dist, pos0 + j, j < len);
+            cc = cn;
+            lb = ln;
+        }
+        pos0 += len;
+    }
+    if (t == 0) cum[cnt] = pos0;
+
+    ScanArgs em;                 // only the fields merge_and_emit reads
+    em.k = a.k;
+    em.nprobe = cnt > 0 ? cnt : 1;
+    em.store_pairs = 0;
+    em.ids = a.ids;
+    em.D = a.D;
+    em.I = a.I;
+    if (cnt == 0 && t == 0) cum[1] = 0;
+    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane, [&](int w, int64_t& lkey, int64_t& loff) {
+        const uint4 m0 = mq[2 * w];
+        lkey = (int64_t)(int32_t)m0.w;
+        loff = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+    });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)pos0);
 }
 
 // ---------------------------------------------------------------------------
@@ -320,8 +581,27 @@ static void launch_line_scan_t(const LineScanArgs& a, int lut_region, size_t sme
     hipLaunchKernelGGL((line_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, lut_region);
 }
 
+template <int KPL>
+static void launch_line16_scan_t(const LineScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(line16_scan_kernel<KPL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL((line16_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, queue_off);
+}
+
 void launch_line_scan(const LineScanArgs& a, hipStream_t s) {
     if (a.nq <= 0) return;
+    if (a.M == 16 && a.ksub == 256 && a.sel_meta) {
+        size_t lutb = (size_t)2 * 4096 * 4 + 256 * 4;      // T23, T4, lambda table; the merge area aliases T23/T4
+        const size_t smem16 = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + 16;
+        if (a.k <= 64) launch_line16_scan_t<1>(a, (int)lutb, smem16, s);
+        else if (a.k <= 256) launch_line16_scan_t<4>(a, (int)lutb, smem16, s);
+        else launch_line16_scan_t<16>(a, (int)lutb, smem16, s);
+        return;
+    }
     size_t lutb = (size_t)2 * a.M * a.ksub * 4;
     const size_t merge = (size_t)4 * a.k * 8;
     if (lutb < merge) lutb = merge;

@@ -15,7 +15,7 @@ struct vlq_line_s {
     std::vector<int64_t> h_line_off, h_line_len;
     AppendWs ws_append;
     std::vector<float> h_lambda;
-    DevBuf ws_near, ws_line, ws_lamf, ws_lamb, ws_res, ws_codes, ws_sel_line, ws_sel_b2, ws_sel_g,
+    DevBuf ws_near, ws_line, ws_lamf, ws_lamb, ws_res, ws_codes, ws_sel_line, ws_sel_b2, ws_sel_g, ws_sel_meta, ws_sel_cnt,
         ws_x, ws_D, ws_I, ws_keys, ws_cdis, stats;
 };
 
@@ -111,7 +111,7 @@ void vlq_line_destroy(vlq_line_t h) {
     DevBuf* bufs[] = {&h->edge_info, &h->edge_dist, &h->lambda_info, &h->codes, &h->lambdas, &h->ids,
                       &h->line_off, &h->line_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
-                      &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_x, &h->ws_D,
+                      &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_sel_meta, &h->ws_sel_cnt, &h->ws_x, &h->ws_D,
                       &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats};
     for (auto b : bufs) b->release();
     if (h->base) vlq_ivfpq_destroy(h->base);
@@ -137,7 +137,8 @@ int vlq_line_set_pq_centroids(vlq_line_t h, const float* c) {
 int vlq_line_set_lambda_codebook(vlq_line_t h, const float* li) {
     if (!h || !li) return fail(VLQ_ERR_INVALID, "null argument");
     TRY(set_dev(h->base));
-    TRY(h->lambda_info.reserve((size_t)h->nlambda * 4));
+    TRY(h->lambda_info.reserve(256 * 4));            // the 16-byte scan copies all 256 slots into LDS
+    HIP_TRY(hipMemsetAsync(h->lambda_info.p, 0, 256 * 4, h->base->stream));
     HIP_TRY(hipMemcpyAsync(h->lambda_info.p, li, (size_t)h->nlambda * 4, hipMemcpyDefault, h->base->stream));
     h->h_lambda.resize(h->nlambda);
     HIP_TRY(hipMemcpyAsync(h->h_lambda.data(), h->lambda_info.p, (size_t)h->nlambda * 4, hipMemcpyDeviceToHost, h->base->stream));
@@ -355,6 +356,8 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
     TRY(h->ws_sel_line.reserve((size_t)n * w1 * 4));
     TRY(h->ws_sel_b2.reserve((size_t)pn * w1 * 4));
     TRY(h->ws_sel_g.reserve((size_t)pn * w1 * 4));
+    TRY(h->ws_sel_meta.reserve((size_t)pn * w1 * sizeof(vlq::LineMeta)));
+    TRY(h->ws_sel_cnt.reserve((size_t)pn * 4));
     TRY(b->ws_qtab.reserve((size_t)pn * E * 4));
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
@@ -365,7 +368,9 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
         vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
                                 h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
-                                sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream);
+                                sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream,
+                                h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
+                                h->ws_sel_meta.as<vlq::LineMeta>(), h->ws_sel_cnt.as<int32_t>());
         // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
         vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
                               b->ws_qtab.as<float>(), b->stream);
@@ -376,6 +381,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
         a.lambda_info = h->lambda_info.as<float>();
         a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();
+        a.sel_meta = h->ws_sel_meta.as<vlq::LineMeta>(); a.sel_cnt = h->ws_sel_cnt.as<int32_t>();
         a.D = (float*)Dd + i0 * k; a.I = (int64_t*)Id + i0 * k;
         a.ncode = h->stats.as<unsigned long long>();
         a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;
