@@ -325,7 +325,7 @@ void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t*
 //     current line is scanned; per-query -2<q, cent> (16 entries per thread) lives in registers;
 //   * one SDWA op per code byte serves both table lookups.
 template <int KPL>
-__global__ __launch_bounds__(256) void line16_scan_kernel(LineScanArgs a, int queue_off) {
+__global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(LineScanArgs a, int queue_off) {
     constexpr int E = 4096, NT = 256, NI = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* t23 = reinterpret_cast<float*>(smraw);                    // [E] at LDS byte 0
