@@ -83,6 +83,32 @@ def test_coarse_bit_exact_vs_oracle(case):
     assert rel.max() <= 1e-5
 
 
+def test_coarse_ties_duplicate_centroids():
+    """Many centroids with bit-identical distance at the nprobe boundary: the reference's heap
+    keeps the lowest columns (strict `<`, columns visited in order, utils.cpp:876-893); the wave
+    select must too, whatever the order its lanes see the columns in."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(77)
+    d, nlist, M, nprobe = 32, 512, 8, 32
+    base = rng.random((8, d)).astype(np.float32)
+    cent = base[rng.integers(0, 8, nlist)]                 # 8 distinct rows, ~64 copies each
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    xq = (base[rng.integers(0, 8, 64)] + 0.01 * rng.standard_normal((64, d))).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, M, 8, cent, pq)
+    for nq in (64, 7):                                     # GEMM path and the < 20 queries path
+        cd, keys = g.coarse_search(xq[:nq], nprobe)
+        cdo, keyso = ox.coarse_search(xq[:nq], nprobe, canonical=True)
+        assert np.array_equal(bits(cd), bits(cdo))
+        assert np.array_equal(keys, keyso)
+        # the lowest columns of the nearest distinct row: 0 .. 31 in column order of that row
+        for i in range(nq):
+            rows = np.flatnonzero((cent == cent[keys[i, 0]]).all(axis=1))
+            assert np.array_equal(keys[i], rows[:nprobe])
+
+
 def test_coarse_small_batch_matches_reference(case):
     """< 20 queries: the reference takes the SSE path (no BLAS) -> bit-exact."""
     if case.n_small == 0:

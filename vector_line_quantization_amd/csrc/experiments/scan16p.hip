@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, VLQ_P_OCC) void scan16p_kernel(ScanArgs a, int
                 float disa = d0a, disb = d0b;
                 adc16_pair(cc, disa, disb, three);
                 sela.offer(disa, posa + j, j < len);
-                selb.offer(disb, posb + j, j < len);
+                selb.template offer<false>(disb, posb + j, j < len);   // b's positions are not visited in order
                 cc = cn;
             }
         } else {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, VLQ_P_OCC) void scan16p_kernel(ScanArgs a, int
                     const uint32_t j = j0 + lane;
                     const uint4 cn = cp[min(j + NT, len - 1)];
                     const float dis = adc16_fixed<0>(cc, dis0, two);
-                    sel.offer(dis, pos0 + j, j < len);
+                    sel.template offer<false>(dis, pos0 + j, j < len);
                     cc = cn;
                 }
             };

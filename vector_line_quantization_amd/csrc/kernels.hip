@@ -436,10 +436,11 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
             float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jn < n4) nxt = row4[jn];
             const bool valid = j4 < n4;
-            sel.offer(cur.x, (uint32_t)(4 * j4 + 0), valid);
-            sel.offer(cur.y, (uint32_t)(4 * j4 + 1), valid);
-            sel.offer(cur.z, (uint32_t)(4 * j4 + 2), valid);
-            sel.offer(cur.w, (uint32_t)(4 * j4 + 3), valid);
+            // columns 4*j4+c, c = 0..3: not in increasing order across the four offers
+            sel.template offer<false>(cur.x, (uint32_t)(4 * j4 + 0), valid);
+            sel.template offer<false>(cur.y, (uint32_t)(4 * j4 + 1), valid);
+            sel.template offer<false>(cur.z, (uint32_t)(4 * j4 + 2), valid);
+            sel.template offer<false>(cur.w, (uint32_t)(4 * j4 + 3), valid);
             cur = nxt;
         }
     } else {

@@ -138,15 +138,21 @@ struct WaveSelect {
         update_threshold();
     }
 
-    // one candidate per lane (`valid` lanes only); wave-uniform control flow
+    // one candidate per lane (`valid` lanes only); wave-uniform control flow.
+    // ORDERED = true: this wave offers its candidates in increasing position, so a candidate whose
+    // distance EQUALS the threshold can never precede the current k-th key and the strict test is
+    // exact.  ORDERED = false (positions arrive out of order): equal distances are queued too and
+    // the full (distance, position) key decides at the merge; FLT_MAX itself is never admitted
+    // (the reference's heap starts at FLT_MAX and admits only `dis < top`, Heap.h:76-78).
+    template <bool ORDERED = true>
     __device__ __forceinline__ void offer(float dis, uint32_t pos, bool valid) {
-        bool pred = valid && (dis < thr);
+        bool pred = valid && (ORDERED ? dis < thr : (dis <= thr && dis < 3.402823466e+38f));
         u64 mask = __ballot(pred);
         if (mask == 0) return;
         int c = __popcll(mask);
         if (npend + c > 64) {
             flush();
-            pred = pred && (dis < thr);
+            pred = pred && (ORDERED ? dis < thr : dis <= thr);
             mask = __ballot(pred);
             if (mask == 0) return;
             c = __popcll(mask);
