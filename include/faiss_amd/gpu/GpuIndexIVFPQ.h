@@ -167,8 +167,15 @@ class GpuIndexIVFPQ : public GpuIndex {
     if (usePrecomputed_) index->precompute_table();
   }
 
-  void reserveMemory(size_t numVecs) { reserveMemoryVecs_ = numVecs; }
-  size_t reclaimMemory() { return 0; }   // lists are stored exactly sized already
+  void reserveMemory(size_t numVecs) {
+    reserveMemoryVecs_ = numVecs;
+    if (h_) VLQ_CHECK(vlq_ivfpq_reserve_memory(h_, (int64_t)numVecs));
+  }
+  size_t reclaimMemory() {
+    uint64_t bytes = 0;
+    if (h_) VLQ_CHECK(vlq_ivfpq_reclaim_memory(h_, &bytes));
+    return (size_t)bytes;
+  }
   void setPrecomputedCodes(bool enable) {
     usePrecomputed_ = enable;
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, enable ? 1 : 0, 0));

@@ -92,6 +92,13 @@ int vlq_ivfpq_set_lists(vlq_ivfpq_t h, const uint8_t* codes, const int64_t* ids,
  * xids may be NULL (ids ntotal..ntotal+n-1).  x [h|d], xids [h|d]. */
 int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids);
 
+/* GpuIndexIVFPQ::reserveMemory (gpu/GpuIndexIVFPQ.cu:283-290 -> IVFBase::reserveMemory,
+ * gpu/impl/IVFBase.cu:62-89): room for num_vecs / nlist vectors in every list, so the adds that
+ * follow append in place.  GpuIndexIVFPQ::reclaimMemory (:323-330 -> IVFBase.cu:136-166): give
+ * the slack back (capacity == length); *bytes_reclaimed (may be NULL) = device bytes freed. */
+int vlq_ivfpq_reserve_memory(vlq_ivfpq_t h, int64_t num_vecs);
+int vlq_ivfpq_reclaim_memory(vlq_ivfpq_t h, uint64_t* bytes_reclaimed);
+
 /* Encode only: assign[n] i64 and codes[n][M] u8 (IndexIVFPQ::encode_multiple with
  * compute_keys=true, IndexIVFPQ.cpp:150-167).  Outputs [h|d]. */
 int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes);

@@ -183,6 +183,20 @@ def test_add_in_batches_appends_on_device(name):
     D, I = g.search(case.xq, case.nprobe, case.k)
     D1, I1 = g1.search(case.xq, case.nprobe, case.k)
     assert np.array_equal(bits(D), bits(D1)) and np.array_equal(I, I1)
+    # reserveMemory / reclaimMemory: layout changes only
+    g4 = gpu_index(case, with_lists=False)
+    g4.reserve_memory(2 * len(case.xb))
+    g4.add(case.xb[:1000], None if case.xids is None else case.xids[:1000])
+    g4.add(case.xb[1000:], None if case.xids is None else case.xids[1000:])
+    assert g4.reclaim_memory() > 0 and g4.reclaim_memory() == 0
+    assert g.reclaim_memory() > 0
+    for gx in (g4, g):
+        for i in range(case.nlist):
+            c, ids = gx.get_list(i)
+            c1, ids1 = g1.get_list(i)
+            assert np.array_equal(ids, ids1) and np.array_equal(c, c1)
+        Dx, Ix = gx.search(case.xq, case.nprobe, case.k)
+        assert np.array_equal(bits(Dx), bits(D1)) and np.array_equal(Ix, I1)
     # packed lists loaded with set_lists and grown by add afterwards
     g2 = gpu_index(case, with_lists=False)
     g2.add(case.xb[:1900], None if case.xids is None else case.xids[:1900])

@@ -699,4 +699,26 @@ int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids)
     return VLQ_OK;
 }
 
+static vlq::ListStore list_store(vlq_ivfpq_t h) {
+    vlq::ListStore ls;
+    ls.nlist = h->nlist; ls.code_size = h->M;
+    ls.codes = &h->codes; ls.ids = &h->ids; ls.off = &h->list_off; ls.len = &h->list_len;
+    ls.h_off = &h->h_list_off; ls.h_len = &h->h_list_len;
+    return ls;
+}
+
+int vlq_ivfpq_reserve_memory(vlq_ivfpq_t h, int64_t num_vecs) {
+    if (!h || num_vecs < 0) return fail(VLQ_ERR_INVALID, "bad argument");
+    TRY(set_dev(h));
+    vlq::ListStore ls = list_store(h);
+    return vlq::lists_reserve(ls, num_vecs, h->stream);
+}
+
+int vlq_ivfpq_reclaim_memory(vlq_ivfpq_t h, uint64_t* bytes_reclaimed) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h));
+    vlq::ListStore ls = list_store(h);
+    return vlq::lists_reclaim(ls, bytes_reclaimed, h->stream);
+}
+
 }  // extern "C"

@@ -32,4 +32,8 @@ int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* a
                  const int32_t* assign32, const uint8_t* new_codes, const uint8_t* new_lambdas,
                  const int64_t* xids, int64_t id_base, hipStream_t s);
 
+int lists_relayout(ListStore& ls, std::vector<int64_t>& new_off, hipStream_t s);
+int lists_reserve(ListStore& ls, int64_t num_vecs, hipStream_t s);
+int lists_reclaim(ListStore& ls, uint64_t* bytes, hipStream_t s);
+
 }  // namespace vlq

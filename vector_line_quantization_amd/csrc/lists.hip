@@ -76,6 +76,68 @@ __global__ void place_kernel(const unsigned long long* __restrict__ sorted, int6
 
 }  // namespace
 
+// move every list to new_off[i] (capacities new_off[i+1] - new_off[i] >= len[i]); synchronises
+int lists_relayout(ListStore& ls, std::vector<int64_t>& new_off, hipStream_t s) {
+    const int64_t nlist = ls.nlist;
+    const int64_t cap = new_off[(size_t)nlist];
+    DevBuf nc, nl, ni, noff;
+    int rc = nc.reserve((size_t)cap * ls.code_size + 16);
+    if (rc == VLQ_OK) rc = ni.reserve((size_t)cap * 8 + 16);
+    if (rc == VLQ_OK && ls.lambdas) rc = nl.reserve((size_t)cap + 16);
+    if (rc == VLQ_OK) rc = noff.reserve(((size_t)nlist + 1) * 8);
+    if (rc != VLQ_OK) { nc.release(); nl.release(); ni.release(); noff.release(); return rc; }
+    hipError_t e = hipMemcpyAsync(noff.p, new_off.data(), ((size_t)nlist + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && ls.codes->p) {
+        const unsigned g = (unsigned)std::min<int64_t>(nlist, 65535 * 16);
+        hipLaunchKernelGGL(relayout_kernel, dim3(g), dim3(256), 0, s, ls.codes->as<uint8_t>(),
+                           ls.lambdas ? ls.lambdas->as<uint8_t>() : nullptr, ls.ids->as<int64_t>(),
+                           ls.off->as<int64_t>(), ls.len->as<int64_t>(), noff.as<int64_t>(), nlist,
+                           ls.code_size, nc.as<uint8_t>(), ls.lambdas ? nl.as<uint8_t>() : nullptr,
+                           ni.as<int64_t>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // new_off (host) and the old buffers die below
+    if (e != hipSuccess) {
+        nc.release(); nl.release(); ni.release(); noff.release();
+        return fail(VLQ_ERR_HIP, "list relayout failed: %s", hipGetErrorString(e));
+    }
+    std::swap(*ls.codes, nc);
+    std::swap(*ls.ids, ni);
+    if (ls.lambdas) std::swap(*ls.lambdas, nl);
+    std::swap(*ls.off, noff);
+    nc.release(); nl.release(); ni.release(); noff.release();
+    ls.h_off->swap(new_off);
+    return VLQ_OK;
+}
+
+// room for num_vecs / nlist vectors in every list (IVFBase::reserveMemory, gpu/impl/IVFBase.cu:62-89)
+int lists_reserve(ListStore& ls, int64_t num_vecs, hipStream_t s) {
+    const int64_t per = num_vecs / ls.nlist;
+    if (per < 1) return VLQ_OK;
+    const std::vector<int64_t>& h_off = *ls.h_off;
+    bool change = false;
+    std::vector<int64_t> new_off((size_t)ls.nlist + 1, 0);
+    for (int64_t i = 0; i < ls.nlist; i++) {
+        const int64_t cap = h_off[(size_t)i + 1] - h_off[(size_t)i];
+        if (cap < per) change = true;
+        new_off[(size_t)i + 1] = new_off[(size_t)i] + std::max(cap, per);
+    }
+    return change ? lists_relayout(ls, new_off, s) : VLQ_OK;
+}
+
+// capacity == length for every list (IVFBase::reclaimMemory, gpu/impl/IVFBase.cu:136-166);
+// *bytes = device bytes given back
+int lists_reclaim(ListStore& ls, uint64_t* bytes, hipStream_t s) {
+    const std::vector<int64_t>& h_len = *ls.h_len;
+    const int64_t old_cap = (*ls.h_off)[(size_t)ls.nlist];
+    std::vector<int64_t> new_off((size_t)ls.nlist + 1, 0);
+    for (int64_t i = 0; i < ls.nlist; i++) new_off[(size_t)i + 1] = new_off[(size_t)i] + h_len[(size_t)i];
+    const int64_t new_cap = new_off[(size_t)ls.nlist];
+    if (bytes) *bytes = (uint64_t)(old_cap - new_cap) * (uint64_t)(ls.code_size + 8 + (ls.lambdas ? 1 : 0));
+    if (new_cap == old_cap) return VLQ_OK;
+    return lists_relayout(ls, new_off, s);
+}
+
 int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* assign64,
                  const int32_t* assign32, const uint8_t* new_codes, const uint8_t* new_lambdas,
                  const int64_t* xids, int64_t id_base, hipStream_t s) {
@@ -122,36 +184,11 @@ int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* a
         std::vector<int64_t> new_off((size_t)nlist + 1, 0);
         for (int64_t i = 0; i < nlist; i++) {
             const int64_t need = h_len[(size_t)i] + cnt[(size_t)i];
-            new_off[(size_t)i + 1] = new_off[(size_t)i] + need + need / 4;
+            // never shrink a list that was given room by reserve
+            const int64_t cap = std::max(need + need / 4, h_off[(size_t)i + 1] - h_off[(size_t)i]);
+            new_off[(size_t)i + 1] = new_off[(size_t)i] + cap;
         }
-        const int64_t cap = new_off[(size_t)nlist];
-        DevBuf nc, nl, ni, noff;
-        int rc = nc.reserve((size_t)cap * ls.code_size + 16);
-        if (rc == VLQ_OK) rc = ni.reserve((size_t)cap * 8 + 16);
-        if (rc == VLQ_OK && ls.lambdas) rc = nl.reserve((size_t)cap + 16);
-        if (rc == VLQ_OK) rc = noff.reserve(((size_t)nlist + 1) * 8);
-        if (rc != VLQ_OK) { nc.release(); nl.release(); ni.release(); noff.release(); return rc; }
-        hipError_t e = hipMemcpyAsync(noff.p, new_off.data(), ((size_t)nlist + 1) * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && ls.codes->p) {
-            const unsigned g = (unsigned)std::min<int64_t>(nlist, 65535 * 16);
-            hipLaunchKernelGGL(relayout_kernel, dim3(g), dim3(256), 0, s, ls.codes->as<uint8_t>(),
-                               ls.lambdas ? ls.lambdas->as<uint8_t>() : nullptr, ls.ids->as<int64_t>(),
-                               ls.off->as<int64_t>(), ls.len->as<int64_t>(), noff.as<int64_t>(), nlist,
-                               ls.code_size, nc.as<uint8_t>(), ls.lambdas ? nl.as<uint8_t>() : nullptr,
-                               ni.as<int64_t>());
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);   // new_off (host) and the old buffers die below
-        if (e != hipSuccess) {
-            nc.release(); nl.release(); ni.release(); noff.release();
-            return fail(VLQ_ERR_HIP, "list relayout failed: %s", hipGetErrorString(e));
-        }
-        std::swap(*ls.codes, nc);
-        std::swap(*ls.ids, ni);
-        if (ls.lambdas) std::swap(*ls.lambdas, nl);
-        std::swap(*ls.off, noff);
-        nc.release(); nl.release(); ni.release(); noff.release();
-        h_off.swap(new_off);
+        TRY(lists_relayout(ls, new_off, s));
     }
 
     // 3. place the batch, then publish the new lengths

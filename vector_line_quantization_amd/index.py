@@ -98,6 +98,16 @@ class GpuIVFPQ:
         pi, _b = _ptr(xids, np.int64)
         check(lib().vlq_ivfpq_add(self._h, C.c_int64(n), px, pi))
 
+    def reserve_memory(self, num_vecs):
+        """GpuIndexIVFPQ::reserveMemory: room for num_vecs / nlist vectors in every list."""
+        check(lib().vlq_ivfpq_reserve_memory(self._h, C.c_int64(num_vecs)))
+
+    def reclaim_memory(self):
+        """GpuIndexIVFPQ::reclaimMemory: drop the append slack; returns the device bytes freed."""
+        n = C.c_uint64()
+        check(lib().vlq_ivfpq_reclaim_memory(self._h, C.byref(n)))
+        return n.value
+
     def encode(self, x):
         n = x.shape[0]
         px, _a = _ptr(x, np.float32)
