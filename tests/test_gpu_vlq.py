@@ -109,6 +109,36 @@ def test_m16_8bit_d128_shape():
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
 
 
+@pytest.fixture(scope="module")
+def world16():
+    """16-byte codes, enough lines for w1 = 1024, many empty and a few over-long lines."""
+    return make_vlq(seed=11, d=96, nlist=200, M=16, nbits=8, nedge=8, nlambda=256, nb=20000)
+
+
+@pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (16, 128, 128), (64, 300, 300), (8, 64, 1),
+                                         (128, 1024, 128), (200, 1024, 1000), (3, 5, 64)])
+def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k):
+    """line16_scan_kernel (anchor-grouped lines, compact line records, two-table gathers) against
+    the oracle over the selection sizes of the wave select (w1 -> 1/4/16 keys per lane, k likewise)."""
+    v, _, xq = world16
+    g = gpu_from_oracle(v)
+    D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
+    Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    assert g.stats() == v.last_ncode
+
+
+def test_m16_line_cap_and_big_batch():
+    v, xb, xq = make_vlq(seed=13, d=128, nlist=6, M=16, nbits=8, nedge=2, nlambda=32, nb=9000)
+    assert np.diff(v.line_off).max() > 1024
+    g = gpu_from_oracle(v)
+    xq = np.concatenate([xq] * 30)          # 1200 queries: several waves of workgroups
+    D, I = g.search(xq, 6, 12, 20)
+    Do, Io = v.search(xq, 6, 12, 20)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
 def test_error_paths(world):
     v, _, xq = world
     g = vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, v.nedge, v.nlambda)
