@@ -90,3 +90,41 @@ def test_more_probes_never_hurt(world):
     g, xq = world["g"], world["xq"][:2000]
     D64, _ = g.search(xq, 64, K)
     assert (D64 <= world["D"][:2000]).all()
+
+
+def test_many_lists_deep1b_shape():
+    """The Deep1B driver's shape scaled down (BASELINE configs[3]: d=96 -> dsub=6, nlist 2^15 here
+    instead of 2^17, M=16, nprobe=128): many short lists, per-query tables from the table kernel
+    (no fused d=128 path), 32 k-row term2, select over 32 k columns, device-side add."""
+    d, nlist, nb, nq, nprobe, k = 96, 32768, 300000, 1500, 128, 10
+    rng = np.random.default_rng(9)
+    coarse = rng.random((nlist, d), dtype=np.float32)
+    pq = (rng.random((16, 256, d // 16), dtype=np.float32) - 0.5) * 0.2
+    xb = (coarse[rng.integers(0, nlist, nb)] + 0.05 * rng.standard_normal((nb, d))).astype(np.float32)
+    xq = (coarse[rng.integers(0, nlist, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, 16, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    g.add(xb[:200000])
+    g.add(xb[200000:])
+    assert g.ntotal == nb
+    D, I = g.search(xq, nprobe, k)
+    # the lists, bulk-read through the ABI, into the oracle
+    lens = np.array([g.list_length(i) for i in range(nlist)], np.int64)
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    codes = np.empty((nb, 16), np.uint8)
+    ids = np.empty((nb,), np.int64)
+    for i in np.flatnonzero(lens):
+        c, ii = g.get_list(int(i))
+        codes[off[i]:off[i + 1]] = c
+        ids[off[i]:off[i + 1]] = ii
+    assert np.array_equal(np.sort(ids), np.arange(nb))
+    ox = pyoracle.OracleIndex(d, nlist, 16, 8, coarse, pq, codes=codes, ids=ids, list_offsets=off)
+    sel = np.arange(0, nq, 50)
+    Do, Io = ox.search(xq[sel], nprobe, k, canonical=True)
+    assert np.array_equal(bits(D[sel]), bits(Do))
+    assert np.array_equal(I[sel], Io)
+    # and a vector finds itself
+    Ds, Is = g.search(xb[:64], nprobe, 1)
+    assert (Is[:, 0] == np.arange(64)).mean() > 0.9
