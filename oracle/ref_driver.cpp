@@ -10,6 +10,9 @@
 // box; the fixtures (data) do.
 //
 // usage: ref_driver <in.bin> <out.bin> [index_file]   (index_file: faiss::write_index of the index)
+//        ref_driver bench <index_file> <in.bin> <out.bin> <nprobe> <k> <reps> <threads>
+//            CPU baseline of bench.py: the reference's own read_index + IndexIVFPQ::search on the
+//            host cores (in.bin: xq[nq*d]; out.bin: D, I of the last run + seconds per run)
 //   in.bin : tagged arrays  cfg[int64 x 16], xt[nt*d], xb[nb*d], xq[nq*d],
 //            optional xids[nb]
 //   cfg = {d, nlist, M, nbits, nt, nb, nq, nprobe, k, max_codes, n_small,
@@ -29,6 +32,11 @@
 #include "IndexPQ.h"
 #include "index_io.h"
 #include "utils.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <chrono>
 
 namespace {
 
@@ -81,7 +89,42 @@ void put(const char* name, char dtype, std::vector<uint64_t> dims, const void* p
 
 }  // namespace
 
+static int bench_main(int argc, char** argv) {
+    if (argc != 9) { fprintf(stderr, "usage: %s bench index_file in.bin out.bin nprobe k reps threads\n", argv[0]); return 1; }
+    const long nprobe = atol(argv[5]), k = atol(argv[6]), reps = atol(argv[7]), threads = atol(argv[8]);
+    omp_set_num_threads((int)threads);
+    faiss::Index* idx = faiss::read_index(argv[2]);          // index_io.cpp:459-532 (precomputes the table)
+    faiss::IndexIVFPQ* index = dynamic_cast<faiss::IndexIVFPQ*>(idx);
+    if (!index) { fprintf(stderr, "not an IndexIVFPQ file\n"); return 1; }
+    auto in = read_tagged(argv[3]);
+    const long nq = (long)in["xq"].dims[0];
+    const float* xq = (const float*)in["xq"].data.data();
+    index->nprobe = nprobe;
+    std::vector<long> I(nq * k);
+    std::vector<float> D(nq * k);
+    index->search(nq, xq, k, D.data(), I.data());             // warm-up
+    std::vector<double> secs;
+    faiss::indexIVFPQ_stats.reset();
+    for (long r = 0; r < reps; r++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        index->search(nq, xq, k, D.data(), I.data());
+        secs.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    g_out = fopen(argv[4], "wb");
+    if (!g_out) { perror(argv[4]); return 1; }
+    put("D", 'f', {(uint64_t)nq, (uint64_t)k}, D.data());
+    put("I", 'l', {(uint64_t)nq, (uint64_t)k}, I.data());
+    std::vector<float> sf(secs.begin(), secs.end());
+    put("seconds", 'f', {(uint64_t)reps}, sf.data());
+    int64_t meta[3] = {index->use_precomputed_table, (int64_t)(faiss::indexIVFPQ_stats.ncode / reps), omp_get_max_threads()};
+    put("meta", 'l', {3}, meta);
+    fclose(g_out);
+    delete idx;
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && strcmp(argv[1], "bench") == 0) return bench_main(argc, argv);
     if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s in.bin out.bin [index_file]\n", argv[0]); return 1; }
     auto in = read_tagged(argv[1]);
     const int64_t* cfg = (const int64_t*)in["cfg"].data.data();

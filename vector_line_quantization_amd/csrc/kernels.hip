@@ -426,22 +426,27 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
     sel.init(nprobe, queue[wave], lane);
     const float* row = dist + q * nlist;
     if ((nlist & 3) == 0) {
-        // 16 B per lane, next 1 KiB of the row requested before the current one is consumed
+        // 16 B per lane; a wave walks its row alone, so the loop is a chain of load latencies unless
+        // several KiB are in flight: 4 x 1 KiB requested ahead of the one being consumed
         const float4* row4 = reinterpret_cast<const float4*>(row);
         const int n4 = nlist >> 2;
-        float4 cur = lane < n4 ? row4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j0 = 0; j0 < n4; j0 += 64) {
-            const int j4 = j0 + lane;
-            const int jn = j4 + 64;
-            float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (jn < n4) nxt = row4[jn];
-            const bool valid = j4 < n4;
-            // columns 4*j4+c, c = 0..3: not in increasing order across the four offers
-            sel.template offer<false>(cur.x, (uint32_t)(4 * j4 + 0), valid);
-            sel.template offer<false>(cur.y, (uint32_t)(4 * j4 + 1), valid);
-            sel.template offer<false>(cur.z, (uint32_t)(4 * j4 + 2), valid);
-            sel.template offer<false>(cur.w, (uint32_t)(4 * j4 + 3), valid);
-            cur = nxt;
+        constexpr int PF = 4;
+        float4 buf[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) buf[u] = row4[min(u * 64 + lane, n4 - 1)];
+        for (int j0 = 0; j0 < n4; j0 += 64 * PF) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int j4 = j0 + u * 64 + lane;
+                const float4 cur = buf[u];
+                buf[u] = row4[min(j4 + 64 * PF, n4 - 1)];          // clamped, unconditional
+                const bool valid = j4 < n4;
+                // columns 4*j4+c, c = 0..3: not in increasing order across the four offers
+                sel.template offer<false>(cur.x, (uint32_t)(4 * j4 + 0), valid);
+                sel.template offer<false>(cur.y, (uint32_t)(4 * j4 + 1), valid);
+                sel.template offer<false>(cur.z, (uint32_t)(4 * j4 + 2), valid);
+                sel.template offer<false>(cur.w, (uint32_t)(4 * j4 + 3), valid);
+            }
         }
     } else {
         for (int j0 = 0; j0 < nlist; j0 += 64) {
