@@ -43,6 +43,29 @@ def test_sample_matches_oracle_bit_exact(world):
     assert np.array_equal(world["I"][sel], Io)
 
 
+def test_full_batch_vs_compiled_reference(world, tmp_path):
+    """All 10 000 queries against the reference's own CPU IndexIVFPQ (oracle/_ref, built from the
+    reference's sources; skipped where that artefact is absent): same probe sets up to the BLAS
+    coarse stage's rounding, and wherever the label agrees the distance agrees to 1e-4 relative
+    (north-star tolerance) -- in practice bit for bit."""
+    from oracle import refbench
+    if not refbench.available():
+        pytest.skip("oracle/_ref not built")
+    ox = world["ox"]
+    path = str(tmp_path / "c1.faissindex")
+    refbench.write_ivfpq_index(path, ox.coarse_centroids, ox.pq_centroids, 8, ox.codes, ox.ids, ox.list_offsets)
+    Dr, Ir, secs, meta = refbench.run_reference(path, world["xq"], NPROBE, K, reps=1, threads=32)
+    D, I = world["D"], world["I"]
+    assert meta[0] == 1
+    from util import label_agreement
+    assert label_agreement(D[::7], I[::7], Dr[::7], Ir[::7]) >= 0.999
+    same = I == Ir
+    assert same.mean() > 0.9
+    rel = np.abs(D[same] - Dr[same]) / np.maximum(np.abs(Dr[same]), 1e-20)
+    assert rel.max() <= 1e-4
+    assert (D.view(np.uint32) == Dr.view(np.uint32)).mean() > 0.999
+
+
 def test_ncode_counter_matches_list_lengths(world):
     g = world["g"]
     g.stats(reset=True)
