@@ -37,9 +37,21 @@ def log(*a):
 # ----------------------------------------------------------------------------
 # synthetic SIFT1M-shaped data (generator G1 of SURVEY.md §8d) and index set-up
 # ----------------------------------------------------------------------------
-def gmm(torch, gen, centres, n, sigma, dev):
+_SUBSPACE = {}
+
+
+def gmm(torch, gen, centres, n, sigma, dev, rank=0, spread=0.0):
     pick = torch.randint(0, centres.shape[0], (n,), generator=gen, device=dev)
     x = centres[pick] + sigma * torch.randn((n, centres.shape[1]), generator=gen, device=dev)
+    if rank > 0:
+        # low intrinsic dimension (what makes real descriptors rankable by 16-byte codes): most of a
+        # point's offset from its centre lies in one fixed `rank`-dimensional subspace
+        key = (rank, centres.shape[1], str(dev))
+        if key not in _SUBSPACE:
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(4242)
+            _SUBSPACE[key] = torch.randn((rank, centres.shape[1]), generator=g2, device=dev) / (rank ** 0.5)
+        x = x + spread * torch.randn((n, rank), generator=gen, device=dev) @ _SUBSPACE[key]
     return torch.clamp(torch.round(x * 255.0), 0, 255).float()
 
 
@@ -69,9 +81,9 @@ def build_index(args, dev):
     gen.manual_seed(1)
     centres = torch.rand((args.gmm_centres, d), generator=gen, device=dev)
     gen.manual_seed(11)
-    xt = gmm(torch, gen, centres, args.nt, args.sigma, dev)
+    xt = gmm(torch, gen, centres, args.nt, args.sigma, dev, args.rank, args.spread)
     gen.manual_seed(22)
-    xb = gmm(torch, gen, centres, args.nb, args.sigma, dev)
+    xb = gmm(torch, gen, centres, args.nb, args.sigma, dev, args.rank, args.spread)
     t0 = time.time()
     gen.manual_seed(1234)
     coarse = kmeans(torch, xt, nlist, 10, gen)
@@ -132,6 +144,8 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--sigma", type=float, default=0.03)
     ap.add_argument("--gmm-centres", type=int, default=2000)
+    ap.add_argument("--rank", type=int, default=0, help="intrinsic dimension of the in-cluster spread (0: isotropic only)")
+    ap.add_argument("--spread", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=10000)
     args = ap.parse_args()
@@ -158,7 +172,7 @@ def main():
     # per-rank query batch (weak scaling: every rank gets its own nq queries)
     gen = torch.Generator(device=dev)
     gen.manual_seed(33 + rank)
-    xq = gmm(torch, gen, centres, args.nq, args.sigma, dev)
+    xq = gmm(torch, gen, centres, args.nq, args.sigma, dev, args.rank, args.spread)
     D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
     I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
     if world > 1:

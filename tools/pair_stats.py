@@ -4,11 +4,12 @@ import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
-args = types.SimpleNamespace(d=128, nlist=4096, M=16, nt=100000, nb=1000000, sigma=0.03, gmm_centres=2000)
+args = types.SimpleNamespace(d=128, nlist=4096, M=16, nt=100000, nb=1000000, sigma=float(os.environ.get('SIGMA', 0.03)), gmm_centres=2000,
+                             rank=int(os.environ.get('RANK_', 0)), spread=float(os.environ.get('SPREAD', 0.0)))
 dev = torch.device("cuda", 0)
 g, centres, coarse, pq, xb = bench.build_index(args, dev)
 gen = torch.Generator(device=dev); gen.manual_seed(33)
-xq = bench.gmm(torch, gen, centres, 10000, args.sigma, dev)
+xq = bench.gmm(torch, gen, centres, 10000, args.sigma, dev, args.rank, args.spread)
 cd, keys = g.coarse_search(xq, 32)
 keys = keys.cpu().numpy()
 order = np.argsort(keys[:, 0], kind="stable")
@@ -23,10 +24,12 @@ print("sorted by (top1,top2): %.2f" % np.mean(shared))
 u, c = np.unique(keys[:, 0], return_counts=True)
 print("distinct top-1 cells:", len(u), "queries in cells with >=2 queries: %.3f" % (c[c >= 2].sum() / len(keys)))
 os.makedirs("gpurun_out", exist_ok=True)
-np.save("gpurun_out/bench_keys.npy", keys.astype(np.int32))
+tag = os.environ.get("TAG", "bench")
+np.save("gpurun_out/%s_keys.npy" % tag, keys.astype(np.int32))
+np.save("gpurun_out/%s_coarse.npy" % tag, coarse.cpu().numpy())
 off = g.list_offsets() if hasattr(g, "list_offsets") else None
 if off is None:
     lens = np.array([g.list_length(i) for i in range(args.nlist)], dtype=np.int64)
 else:
     lens = np.diff(off)
-np.save("gpurun_out/bench_lens.npy", lens)
+np.save("gpurun_out/%s_lens.npy" % tag, lens)

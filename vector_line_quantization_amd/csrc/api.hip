@@ -251,7 +251,8 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_hist.reserve(((size_t)h->nlist + 1) * sizeof(int)));
                 TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
-                                        h->ws_qorder.as<int>(), h->stream);
+                                        h->ws_qorder.as<int>(), h->stream,
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
                 a.qorder = h->ws_qorder.as<int>();
                 tq.stop();
             }
@@ -359,7 +360,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
-                      &h->list_off, &h->list_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->list_off, &h->list_len, &h->list_rank, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats, &h->imi_cent,
@@ -377,6 +378,68 @@ int vlq_ivfpq_set_stream(vlq_ivfpq_t h, void* hip_stream) {
     return VLQ_OK;
 }
 
+// Spatial order of the lists (speed only): recursive two-means bisection of the centroids; lists
+// that are close in space get close ranks.  The scan runs queries in the order of the rank of
+// their nearest list, so workgroups that are resident together on an XCD probe neighbouring
+// lists and find each other's term2 rows in L2.
+static void spatial_list_rank(const float* cent, int nlist, int d, std::vector<int>& rank) {
+    std::vector<int> order((size_t)nlist);
+    for (int i = 0; i < nlist; i++) order[(size_t)i] = i;
+    std::vector<float> ca((size_t)d), cb((size_t)d);
+    std::vector<double> sa((size_t)d), sb((size_t)d);
+    std::vector<char> side;
+    struct Seg { int lo, hi; };
+    std::vector<Seg> stack;
+    stack.push_back({0, nlist});
+    auto dist2 = [&](const float* x, const float* c) {
+        float s = 0.f;
+        for (int j = 0; j < d; j++) { const float t = x[j] - c[j]; s += t * t; }
+        return s;
+    };
+    while (!stack.empty()) {
+        const Seg sg = stack.back();
+        stack.pop_back();
+        const int n = sg.hi - sg.lo;
+        if (n <= 2) continue;
+        int* idx = order.data() + sg.lo;
+        // two far-apart seeds: the point farthest from the first one, then the farthest from that
+        const float* p0 = cent + (size_t)idx[0] * d;
+        int fb = 0; float best = -1.f;
+        for (int i = 0; i < n; i++) { const float v = dist2(cent + (size_t)idx[i] * d, p0); if (v > best) { best = v; fb = i; } }
+        std::copy(cent + (size_t)idx[fb] * d, cent + (size_t)idx[fb] * d + d, cb.begin());
+        int fa = 0; best = -1.f;
+        for (int i = 0; i < n; i++) { const float v = dist2(cent + (size_t)idx[i] * d, cb.data()); if (v > best) { best = v; fa = i; } }
+        std::copy(cent + (size_t)idx[fa] * d, cent + (size_t)idx[fa] * d + d, ca.begin());
+        side.assign((size_t)n, 0);
+        int na = 0;
+        for (int it = 0; it < 4; it++) {
+            std::fill(sa.begin(), sa.end(), 0.0);
+            std::fill(sb.begin(), sb.end(), 0.0);
+            na = 0;
+            for (int i = 0; i < n; i++) {
+                const float* x = cent + (size_t)idx[i] * d;
+                const bool toa = dist2(x, ca.data()) < dist2(x, cb.data());
+                side[(size_t)i] = toa;
+                std::vector<double>& acc = toa ? sa : sb;
+                for (int j = 0; j < d; j++) acc[(size_t)j] += x[j];
+                na += toa;
+            }
+            if (na == 0 || na == n) break;
+            for (int j = 0; j < d; j++) { ca[(size_t)j] = (float)(sa[(size_t)j] / na); cb[(size_t)j] = (float)(sb[(size_t)j] / (n - na)); }
+        }
+        if (na == 0 || na == n) continue;        // duplicates: leave the segment as it is
+        // stable partition: side a first
+        std::vector<int> tmp((size_t)n);
+        int pa = 0, pb = na;
+        for (int i = 0; i < n; i++) tmp[(size_t)(side[(size_t)i] ? pa++ : pb++)] = idx[i];
+        std::copy(tmp.begin(), tmp.end(), idx);
+        stack.push_back({sg.lo, sg.lo + na});
+        stack.push_back({sg.lo + na, sg.hi});
+    }
+    rank.assign((size_t)nlist, 0);
+    for (int i = 0; i < nlist; i++) rank[(size_t)order[(size_t)i]] = i;
+}
+
 int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     if (!h || !centroids) return fail(VLQ_ERR_INVALID, "null argument");
     TRY(set_dev(h));
@@ -388,6 +451,16 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     vlq::launch_row_norms(h->coarse.as<float>(), h->nlist, h->d, h->cnorm.as<float>(), h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_rank = false;
+    if (h->nlist <= (1 << 22)) {
+        std::vector<float> hc((size_t)h->nlist * h->d);
+        HIP_TRY(hipMemcpy(hc.data(), h->coarse.p, bytes, hipMemcpyDeviceToHost));
+        std::vector<int> rank;
+        spatial_list_rank(hc.data(), h->nlist, h->d, rank);
+        TRY(h->list_rank.reserve((size_t)h->nlist * sizeof(int)));
+        HIP_TRY(hipMemcpy(h->list_rank.p, rank.data(), (size_t)h->nlist * sizeof(int), hipMemcpyHostToDevice));
+        h->have_rank = true;
+    }
     h->have_coarse = true;
     h->imi_nbits = 0;
     h->term2_valid = false;

@@ -87,6 +87,8 @@ struct vlq_ivfpq_s {
 
     // inverted lists: list i at [list_off[i], list_off[i] + list_len[i]), capacity list_off[i+1] - list_off[i]
     DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off, list_len;
+    DevBuf list_rank;             // [nlist] int: spatial order of the lists (query scheduling only)
+    bool have_rank = false;
     // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,
     // and the kc virtual full vectors whose term2 rows make table type 2
     int imi_nbits = 0;

@@ -66,8 +66,9 @@ void launch_scan16w(const ScanArgs& a, int nw, hipStream_t s);
 bool scan16p_supports(const ScanArgs& a);
 void launch_scan16p(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
+// list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s);
+                        int* qorder, hipStream_t s, const int* list_rank = nullptr);
 
 // merge of per-shard results [nparts][nq][k] into the global top-k (list-sharded multi-GPU mode)
 void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,

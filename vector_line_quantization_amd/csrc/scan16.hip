@@ -10,7 +10,9 @@
 //   * double-buffered LDS LUT, one workgroup barrier per probe;
 //   * workgroups are dealt to XCDs so that queries adjacent in `qorder` (sorted by
 //     nearest coarse centroid) share an L2: their term2 rows and list codes are then
-//     mostly L2 hits instead of fabric reads.  Placement only affects speed.
+//     mostly L2 hits instead of fabric reads.  Placement only affects speed.  (Walking a
+//     query's probes in the spatial order of their lists as well was measured and does not
+//     pay: the nearest lists must come first to tighten the admission threshold.)
 #include <type_traits>
 
 #include "kernels.h"
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     ProbeMeta pm;
     pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64), a.nprobe);
     int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) +
-                                               ProbeMeta::bytes(a.nprobe));
+                                               ProbeMeta::bytes(a.nprobe));    // cut, nlive
+    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // adc16_fixed() addresses the LUT buffers at LDS offsets 0 / 16384
@@ -52,18 +55,23 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     // ---- per-query set-up -------------------------------------------------------
     const bool badkey = probe_meta_fill(a, q, pm, t, NT);
     float4 m2t3[NI];
-#if defined(VLQ_ABLB) && (VLQ_ABLB & 2)
-    for (int i = 0; i < NI; i++) m2t3[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
     load_query_table16<NI>(a, q, t, lane, wave, m2t3);
-#endif
     __syncthreads();
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
-        if (lane == 0) misc[0] = cut;
+        __builtin_amdgcn_wave_barrier();
+        int nl = 0;
+        for (int p0 = 0; p0 < cut; p0 += 64) {      // coarse-distance order, dead probes dropped
+            const int p = p0 + lane;
+            const bool lv = p < cut && pm.pkey[p] >= 0;
+            const u64 mask = __ballot(lv);
+            if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
+            nl += __popcll(mask);
+        }
+        if (lane == 0) { misc[0] = cut; misc[1] = nl; }
     }
     __syncthreads();
-    const int np_eff = misc[0];
+    const int nlive = misc[1];
 
     WaveSelect<KPL> sel;
     sel.init(a.k, queue + wave * 64, lane);
@@ -71,38 +79,32 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
     uint4 c0 = make_uint4(0, 0, 0, 0);
-    auto prefetch = [&](int p) {
-        // first live probe at or after p; returns its index (or np_eff)
-        while (p < np_eff && pm.pkey[p] < 0) p++;
-        if (p < np_eff) {
-            const int64_t key = pm.pkey[p];
-            if (a.imi_nbits > 0) {
-                // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
-                // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
-                const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
+    auto prefetch = [&](int i) {     // i-th probe of the walking order
+        if (i >= nlive) return;
+        const int p = ord[i];
+        const int64_t key = pm.pkey[p];
+        if (a.imi_nbits > 0) {
+            // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
+            // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
+            const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
 #pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const int64_t ki = (NW * i + wave) < 8 ? ki0 : ki1;
-                    t2r[i] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i * NT + t];
-                }
-            } else {
-                const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)key * E);
-#pragma unroll
-                for (int i = 0; i < NI; i++) t2r[i] = src[i * NT + t];
+            for (int i2 = 0; i2 < NI; i2++) {
+                const int64_t ki = (NW * i2 + wave) < 8 ? ki0 : ki1;
+                t2r[i2] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i2 * NT + t];
             }
-            if ((uint32_t)t < pm.plen[p])
-                c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)key * E);
+#pragma unroll
+            for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
         }
-        return p;
+        if ((uint32_t)t < pm.plen[p])
+            c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
     };
-#if defined(VLQ_ABLB) && (VLQ_ABLB & 1)
-    int ik = np_eff;            // kernel experiments: no probe loop
-#else
-    int ik = prefetch(0);
-#endif
+    prefetch(0);
     int buf = 0;
     uint64_t nscan = 0;
-    while (ik < np_eff) {
+    for (int i = 0; i < nlive; i++) {
+        const int ik = ord[i];
         const uint32_t len = pm.plen[ik];
         const float dis0 = pm.pd0[ik];
         const uint32_t pos0 = pm.cum[ik];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
         build_lut16<NI>(L, t, t2r, m2t3);
         uint4 cc = c0;
-        const int nxt = prefetch(ik + 1);
+        prefetch(i + 1);
         __syncthreads();
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
@@ -131,7 +133,6 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         else scan_list(std::integral_constant<int, 1>{});
         nscan += len;
         if (NBUF == 2) buf ^= 1;
-        ik = nxt;
     }
 
     merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, q, wave, lane,
@@ -166,7 +167,7 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 4 + 64;
+    const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 64;
     const size_t smem = lutb + tail;
     if (a.k <= 64) launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
     else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
@@ -179,11 +180,12 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
 // workgroups run next to each other, never a result.
 // ---------------------------------------------------------------------------
 __global__ void qorder_hist_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
-                                   int nlist, int* __restrict__ hist) {
+                                   int nlist, int* __restrict__ hist, const int* __restrict__ list_rank) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t k0 = keys[q * nprobe];
-    atomicAdd(&hist[(k0 >= 0 && k0 < nlist) ? (int)k0 : nlist], 1);
+    const bool ok = k0 >= 0 && k0 < nlist;
+    atomicAdd(&hist[ok ? (list_rank ? list_rank[k0] : (int)k0) : nlist], 1);
 }
 
 __global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ hist, int nbins) {
@@ -207,23 +209,25 @@ __global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ his
 }
 
 __global__ void qorder_scatter_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
-                                      int nlist, int* __restrict__ hist, int* __restrict__ qorder) {
+                                      int nlist, int* __restrict__ hist, int* __restrict__ qorder,
+                                      const int* __restrict__ list_rank) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t k0 = keys[q * nprobe];
-    const int pos = atomicAdd(&hist[(k0 >= 0 && k0 < nlist) ? (int)k0 : nlist], 1);
+    const bool ok = k0 >= 0 && k0 < nlist;
+    const int pos = atomicAdd(&hist[ok ? (list_rank ? list_rank[k0] : (int)k0) : nlist], 1);
     qorder[pos] = (int)q;
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s) {
+                        int* qorder, hipStream_t s, const int* list_rank) {
     if (nq <= 0) return;
     (void)hipMemsetAsync(hist, 0, ((size_t)nlist + 1) * sizeof(int), s);
     const unsigned g = (unsigned)((nq + 255) / 256);
-    hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist);
+    hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank);
     hipLaunchKernelGGL(qorder_scan_kernel, dim3(1), dim3(1024), 0, s, hist, nlist + 1);
     hipLaunchKernelGGL(qorder_scatter_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist,
-                       qorder);
+                       qorder, list_rank);
 }
 
 }  // namespace vlq
