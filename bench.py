@@ -162,8 +162,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (tests): take the collective path with a single rank too
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     g, centres, coarse, pq, xb = build_index(args, dev)
@@ -173,45 +178,69 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(33 + rank)
     xq = gmm(torch, gen, centres, args.nq, args.sigma, dev, args.rank, args.spread)
-    D = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev)
-    I = torch.empty((args.nq, args.k), dtype=torch.int64, device=dev)
-    if world > 1:
-        Dall = torch.empty((world * args.nq, args.k), dtype=torch.float32, device=dev)
-        Iall = torch.empty((world * args.nq, args.k), dtype=torch.int64, device=dev)
+    # two result buffer sets: the all-gather of step i (RCCL stream) overlaps the search of step
+    # i+1; a set is reused only after its gather has been waited for
+    Ds = [torch.empty((args.nq, args.k), dtype=torch.float32, device=dev) for _ in range(2)]
+    Is = [torch.empty((args.nq, args.k), dtype=torch.int64, device=dev) for _ in range(2)]
+    D, I = Ds[0], Is[0]
+    if use_dist:
+        Dall = [torch.empty((world * args.nq, args.k), dtype=torch.float32, device=dev) for _ in range(2)]
+        Iall = [torch.empty((world * args.nq, args.k), dtype=torch.int64, device=dev) for _ in range(2)]
+    pend = [None, None]
+    nstep = [0]
+
+    def drain():
+        for b in range(2):
+            if pend[b] is not None:
+                for w in pend[b]:
+                    w.wait()
+                pend[b] = None
 
     def step():
-        g.search(xq, args.nprobe, args.k, D=D, I=I)
-        if world > 1:   # per-shard top-k -> every rank (north star: RCCL all-gather over xGMI)
-            dist.all_gather_into_tensor(Dall, D)
-            dist.all_gather_into_tensor(Iall, I)
+        b = nstep[0] & 1
+        nstep[0] += 1
+        if pend[b] is not None:
+            for w in pend[b]:
+                w.wait()
+            pend[b] = None
+        g.search(xq, args.nprobe, args.k, D=Ds[b], I=Is[b])
+        if use_dist:   # per-shard top-k -> every rank (north star: RCCL all-gather over xGMI)
+            pend[b] = [dist.all_gather_into_tensor(Dall[b], Ds[b], async_op=True),
+                       dist.all_gather_into_tensor(Iall[b], Is[b], async_op=True)]
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     g.stats(reset=True)
     g.profile(True)
     g.profile_read(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                      # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    D, I = Ds[(nstep[0] - 1) & 1], Is[(nstep[0] - 1) & 1]
     prof = g.profile_read(reset=True)
     g.profile(False)
     _nq_stat, ncode = g.stats(reset=True)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the gathered copy of this rank's slice is this rank's result
+        assert torch.equal(Dall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], D)
+        assert torch.equal(Iall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], I)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -366,7 +395,7 @@ def main():
                                              "8..%d tried; affinity mask %d cpus, host %d logical cpus)"
                                              % (ncpu, pyoracle.num_threads(), cores, cores, os.cpu_count())}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
