@@ -452,7 +452,7 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_rank = false;
-    if (h->nlist <= (1 << 22)) {
+    if (h->nlist <= (1 << 17)) {      // O(nlist * d * log nlist) host work; larger indexes keep the list-id order
         std::vector<float> hc((size_t)h->nlist * h->d);
         HIP_TRY(hipMemcpy(hc.data(), h->coarse.p, bytes, hipMemcpyDeviceToHost));
         std::vector<int> rank;
