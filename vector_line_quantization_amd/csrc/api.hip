@@ -265,7 +265,8 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             else if (variant && variant[0] == 'w') vlq::launch_scan16w(a, variant[1] == '2' ? 2 : variant[1] == '1' ? 1 : 4, h->stream);
             else
 #endif
-            vlq::launch_scan16(a, h->stream);
+            if (h->ntotal < (int64_t)h->nlist * 24) vlq::launch_scan16_short(a, h->stream);   // a few codes per list
+            else vlq::launch_scan16(a, h->stream);
             tm.stop();
         } else {
             StageTimer tm(h, 2);

@@ -58,6 +58,8 @@ struct ScanArgs {
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
+// same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
+void launch_scan16_short(const ScanArgs& a, hipStream_t s);
 // second generation: whole-probe prefetch, scalar list bases (scan16v2.hip)
 void launch_scan16v2(const ScanArgs& a, hipStream_t s);
 // wave-autonomous variant (scan16w.hip): nw = 2 or 4 waves per workgroup

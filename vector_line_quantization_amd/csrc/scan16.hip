@@ -141,6 +141,137 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     if (badkey) *a.bad_key = 1;
 }
 
+// ---------------------------------------------------------------------------
+// Short-list variant (inverted multi-index and other many-list indexes: a few codes per
+// list).  Building a 4096-entry LUT per probe to look up 16 x a-handful of entries is what
+// the reference does (precompute_list_tables_L2 per probed list) and what bounds scan16_kernel
+// there.  Here no LUT is built: the per-query part (-2 <q, cent>, 16 KB) sits in LDS once
+// per query, each wave walks its own probes (no workgroup barrier in the loop), and a lane
+// fetches exactly the 16 term2 entries its code addresses and forms the SAME table entries
+// term2 + (-2 <q, cent>) (fvec_madd, IndexIVFPQ.cpp:641-644) before the left-to-right sum:
+// identical arithmetic, identical results.
+// ---------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void scan16_short_kernel(ScanArgs a, int queue_off) {
+    constexpr int E = 4096, NW = 4, NT = 256, NI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* qtl = reinterpret_cast<float*>(smraw);                         // [16][256] -2 <q_m, cent_mj>
+    u64* queue = reinterpret_cast<u64*>(smraw + queue_off);               // [NW][64]
+    ProbeMeta pm;
+    pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64), a.nprobe);
+    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) +
+                                               ProbeMeta::bytes(a.nprobe));
+    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int64_t q;
+    {
+        const int64_t b = blockIdx.x;
+        const int64_t s = (b & 7) * a.xcd_chunk + (b >> 3);
+        if (s >= a.nq) return;
+        q = a.qorder ? a.qorder[s] : s;
+    }
+    const int64_t* kq = a.keys + q * a.nprobe;
+    const bool badkey = probe_meta_fill(a, q, pm, t, NT);
+    {
+        float4 m2t3[NI];
+        load_query_table16<NI>(a, q, t, lane, t >> 6, m2t3);
+#pragma unroll
+        for (int i = 0; i < NI; i++) reinterpret_cast<float4*>(qtl)[i * NT + t] = m2t3[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int cut = probe_meta_scan(a, pm, lane);
+        __builtin_amdgcn_wave_barrier();
+        int nl = 0;
+        for (int p0 = 0; p0 < cut; p0 += 64) {
+            const int p = p0 + lane;
+            const bool lv = p < cut && pm.pkey[p] >= 0;
+            const u64 mask = __ballot(lv);
+            if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
+            nl += __popcll(mask);
+        }
+        if (lane == 0) { misc[0] = cut; misc[1] = nl; }
+    }
+    __syncthreads();
+    const int nlive = misc[1];
+
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+    const uint4* codes = reinterpret_cast<const uint4*>(a.codes);
+    auto first_chunk = [&](int i) {
+        if (i >= nlive) return make_uint4(0, 0, 0, 0);
+        const int p = ord[i];
+        return codes[pm.poff[p] + min((uint32_t)lane, pm.plen[p] - 1)];
+    };
+    uint4 cnext = first_chunk(wave);
+    for (int i = wave; i < nlive; i += NW) {          // this wave's probes, in increasing scan position
+        const int p = ord[i];
+        const uint32_t len = pm.plen[p];
+        const float dis0 = pm.pd0[p];
+        const uint32_t pos0 = pm.cum[p];
+        const int64_t key = pm.pkey[p];
+        const uint4* cp = codes + pm.poff[p];
+        const float* row0;
+        const float* row1;
+        if (a.imi_nbits > 0) {      // table type 2 (IndexIVFPQ.cpp:645-686): halves from two rows
+            row0 = a.term2 + (size_t)(key & ((int64_t(1) << a.imi_nbits) - 1)) * E;
+            row1 = a.term2 + (size_t)(key >> a.imi_nbits) * E;
+        } else {
+            row0 = row1 = a.term2 + (size_t)key * E;
+        }
+        uint4 cc = cnext;
+        cnext = first_chunk(i + NW);
+        for (uint32_t j0 = 0; j0 < len; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const uint4 cn = cp[min(j + 64, len - 1)];
+            const uint32_t w[4] = {cc.x, cc.y, cc.z, cc.w};
+            float e[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint32_t c = (w[m >> 2] >> (8 * (m & 3))) & 255u;
+                const float t2 = (m < 8 ? row0 : row1)[m * 256 + c];
+                e[m] = __fadd_rn(t2, qtl[m * 256 + c]);
+            }
+            float dis = dis0;
+#pragma unroll
+            for (int m = 0; m < 16; m++) dis = __fadd_rn(dis, e[m]);
+            sel.offer(dis, pos0 + j, j < len);
+            cc = cn;
+        }
+    }
+    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, q, wave, lane,
+                            [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)pm.cum[a.nprobe]);
+    if (badkey) *a.bad_key = 1;
+}
+
+template <int KPL>
+static void launch_scan16_short_t(const ScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_short_kernel<KPL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_smem = smem;
+    }
+    const unsigned grid = (unsigned)(8 * a.xcd_chunk);
+    hipLaunchKernelGGL((scan16_short_kernel<KPL>), dim3(grid), dim3(256), smem, s, a, queue_off);
+}
+
+void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
+    if (a_in.nq <= 0) return;
+    ScanArgs a = a_in;
+    a.xcd_chunk = (int)((a.nq + 7) / 8);
+    size_t region = (size_t)4096 * 4;                        // the merge area aliases the table
+    const size_t merge = (size_t)4 * a.k * 8;
+    if (region < merge) region = merge;
+    const size_t smem = region + (size_t)4 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 64;
+    if (a.k <= 64) launch_scan16_short_t<1>(a, (int)region, smem, s);
+    else if (a.k <= 256) launch_scan16_short_t<4>(a, (int)region, smem, s);
+    else launch_scan16_short_t<16>(a, (int)region, smem, s);
+}
+
 template <int KPL, int NW, int NBUF>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
     static size_t attr_smem = 0;
@@ -180,12 +311,13 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
 // workgroups run next to each other, never a result.
 // ---------------------------------------------------------------------------
 __global__ void qorder_hist_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
-                                   int nlist, int* __restrict__ hist, const int* __restrict__ list_rank) {
+                                   int nlist, int* __restrict__ hist, const int* __restrict__ list_rank,
+                                   int shift, int nbins) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t k0 = keys[q * nprobe];
     const bool ok = k0 >= 0 && k0 < nlist;
-    atomicAdd(&hist[ok ? (list_rank ? list_rank[k0] : (int)k0) : nlist], 1);
+    atomicAdd(&hist[ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1], 1);
 }
 
 __global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ hist, int nbins) {
@@ -210,24 +342,30 @@ __global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ his
 
 __global__ void qorder_scatter_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
                                       int nlist, int* __restrict__ hist, int* __restrict__ qorder,
-                                      const int* __restrict__ list_rank) {
+                                      const int* __restrict__ list_rank, int shift, int nbins) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t k0 = keys[q * nprobe];
     const bool ok = k0 >= 0 && k0 < nlist;
-    const int pos = atomicAdd(&hist[ok ? (list_rank ? list_rank[k0] : (int)k0) : nlist], 1);
+    const int pos = atomicAdd(&hist[ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1], 1);
     qorder[pos] = (int)q;
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank) {
     if (nq <= 0) return;
-    (void)hipMemsetAsync(hist, 0, ((size_t)nlist + 1) * sizeof(int), s);
+    // at most 16 Ki bins (the prefix scan is one workgroup): many-list indexes are binned by the
+    // high bits of the list id / rank -- for a multi-index key that is its second sub-index
+    int shift = 0;
+    while (((int64_t)nlist >> shift) > 16384) shift++;
+    const int nbins = (int)(((int64_t)nlist - 1) >> shift) + 2;        // last bin: invalid keys
+    (void)hipMemsetAsync(hist, 0, (size_t)nbins * sizeof(int), s);
     const unsigned g = (unsigned)((nq + 255) / 256);
-    hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank);
-    hipLaunchKernelGGL(qorder_scan_kernel, dim3(1), dim3(1024), 0, s, hist, nlist + 1);
+    hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank,
+                       shift, nbins);
+    hipLaunchKernelGGL(qorder_scan_kernel, dim3(1), dim3(1024), 0, s, hist, nbins);
     hipLaunchKernelGGL(qorder_scatter_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist,
-                       qorder, list_rank);
+                       qorder, list_rank, shift, nbins);
 }
 
 }  // namespace vlq
