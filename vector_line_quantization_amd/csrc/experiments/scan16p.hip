@@ -328,12 +328,7 @@ __global__ __launch_bounds__(256, VLQ_P_OCC) void scan16p_kernel(ScanArgs a, int
 
 template <int KPL>
 static void launch_scan16p_t(const ScanArgs& a, int meta_bytes, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16p_kernel<KPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16p_kernel<KPL>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
     hipLaunchKernelGGL((scan16p_kernel<KPL>), dim3(grid), dim3(256), smem, s, a, meta_bytes);
 }

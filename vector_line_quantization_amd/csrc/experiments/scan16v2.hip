@@ -199,12 +199,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 3) void scan16v2_kernel(ScanArg
 
 template <int KPL>
 static void launch_scan16v2_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16v2_kernel<KPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16v2_kernel<KPL>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
     hipLaunchKernelGGL((scan16v2_kernel<KPL>), dim3(grid), dim3(256), smem, s, a, lut_region);
 }

@@ -241,12 +241,7 @@ extern "C" int vlq_debug_stamps(unsigned long long* out, int reset) {
 
 template <int KPL, int NW>
 static void launch_scan16w_t(const ScanArgs& a, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16w_kernel<KPL, NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16w_kernel<KPL, NW>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
     hipLaunchKernelGGL((scan16w_kernel<KPL, NW>), dim3(grid), dim3(64 * NW), smem, s, a);
 }

@@ -6,6 +6,11 @@
 
 namespace vlq {
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) to `bytes` on
+// the CURRENT device.  The attribute is per device and the library may serve several devices
+// (and host threads) of one process, so the high-water mark is kept per (kernel, device).
+void ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // row norms in the reference's SSE order (utils.cpp:538-556, :675-682)
 void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s);
 

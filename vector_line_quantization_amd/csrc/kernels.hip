@@ -11,11 +11,28 @@
 //                                                        -> scan_kernel
 //   compute_code                ProductQuantizer.cpp:311-336 -> encode_kernel
 #include "kernels.h"
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include "sse_order.cuh"
 #include "wave_topk.cuh"
 #include "scan_common.cuh"
 
 namespace vlq {
+
+void ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> high;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& h = high[std::make_pair(kernel, dev)];
+    if (bytes > h) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        h = bytes;
+    }
+}
 
 #define FLT_MAX_F 3.402823466e+38f
 
@@ -328,12 +345,7 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
                                float* out, int64_t nq, int nlist, int d, hipStream_t s) {
     constexpr int S = 4 * NU + 4;
     const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC>), smem);
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
     // tiles per workgroup: the MFMA pipe of a CU is shared by its (up to 2) resident
@@ -370,12 +382,7 @@ void launch_coarse_distances(const float* q, const float* c, const float* qn, co
     }
     constexpr int KC = 64;
     const size_t smem = 2 * 2 * 128 * (KC / 2 + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_dist_kernel<KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_kernel<KC>), smem);
     dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nq + 127) / 128));
     hipLaunchKernelGGL(coarse_dist_kernel<KC>, grid, dim3(256), smem, s, q, c, qn, cn, out, nq,
                        nlist, d);
@@ -737,12 +744,7 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a, int nbuf, int lut
 
 template <int KPL, bool FAST16>
 static void launch_scan_t(const ScanArgs& a, int nbuf, int lut_region, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan_kernel<KPL, FAST16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan_kernel<KPL, FAST16>), smem);
     hipLaunchKernelGGL((scan_kernel<KPL, FAST16>), dim3((unsigned)a.nq), dim3(256), smem, s, a, nbuf,
                        lut_region);
 }

@@ -572,23 +572,13 @@ __global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_
 
 template <int KPL>
 static void launch_line_scan_t(const LineScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(line_scan_kernel<KPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(line_scan_kernel<KPL>), smem);
     hipLaunchKernelGGL((line_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, lut_region);
 }
 
 template <int KPL>
 static void launch_line16_scan_t(const LineScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(line16_scan_kernel<KPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(line16_scan_kernel<KPL>), smem);
     hipLaunchKernelGGL((line16_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, queue_off);
 }
 

@@ -249,12 +249,7 @@ __global__ __launch_bounds__(256) void scan16_short_kernel(ScanArgs a, int queue
 
 template <int KPL>
 static void launch_scan16_short_t(const ScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_short_kernel<KPL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_short_kernel<KPL>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
     hipLaunchKernelGGL((scan16_short_kernel<KPL>), dim3(grid), dim3(256), smem, s, a, queue_off);
 }
@@ -274,12 +269,7 @@ void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
 
 template <int KPL, int NW, int NBUF>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_smem = smem;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
     hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
