@@ -476,11 +476,99 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(const float* __restr
     }
 }
 
+// Row-in-registers select for nprobe <= 64 and rows of at most 256 * NV floats (nlist = 4096:
+// NV = 16): a wave pulls its whole row with NV outstanding 16-byte loads per lane, takes the
+// nprobe-th smallest of the 64 per-lane minima as a cut -- an upper bound of the nprobe-th
+// smallest element, because nprobe distinct elements lie at or below it -- and only the few
+// dozen elements at or below the cut enter the exact (distance, column) selection.  Elements at
+// FLT_MAX are never admitted (the reference heap starts there, Heap.h:76-78).
+template <int NV>
+__global__ __launch_bounds__(256) void coarse_select_reg_kernel(const float* __restrict__ dist, int64_t nq,
+                                                                int nlist, int nprobe, float* __restrict__ cdis,
+                                                                int64_t* __restrict__ keys) {
+    constexpr int CAP = 512;                    // candidates at or below the cut, per row
+    __shared__ u64 queue[4][64];
+    __shared__ u64 cand[4][CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const float4* row4 = reinterpret_cast<const float4*>(dist + q * nlist);
+    const int n4 = nlist >> 2;
+    float4 v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; u++) v[u] = row4[min(u * 64 + lane, n4 - 1)];    // clamped; masked below
+    float mn = FLT_MAX_F;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        if (u * 64 + lane >= n4) v[u] = make_float4(FLT_MAX_F, FLT_MAX_F, FLT_MAX_F, FLT_MAX_F);
+        mn = fminf(mn, fminf(fminf(v[u].x, v[u].y), fminf(v[u].z, v[u].w)));
+    }
+    // cut = nprobe-th smallest lane minimum (lanes whose minimum is FLT_MAX hold nothing admissible)
+    const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
+    const float cut = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));
+    auto pass = [&](float x) { return x <= cut && x < FLT_MAX_F; };
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < NV; u++) cnt += (int)pass(v[u].x) + (int)pass(v[u].y) + (int)pass(v[u].z) + (int)pass(v[u].w);
+    int incl = cnt;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int o = __shfl_up(incl, sft, 64);
+        if (lane >= sft) incl += o;
+    }
+    const int total = __shfl(incl, 63, 64);
+    WaveSelect<1> sel;
+    sel.init(nprobe, queue[wave], lane);
+    if (total <= CAP) {
+        int pos = incl - cnt;
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const uint32_t c0 = (uint32_t)(4 * (u * 64 + lane));
+            if (pass(v[u].x)) cand[wave][pos++] = make_key(v[u].x, c0 + 0);
+            if (pass(v[u].y)) cand[wave][pos++] = make_key(v[u].y, c0 + 1);
+            if (pass(v[u].z)) cand[wave][pos++] = make_key(v[u].z, c0 + 2);
+            if (pass(v[u].w)) cand[wave][pos++] = make_key(v[u].w, c0 + 3);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int c0 = 0; c0 < total; c0 += 64) {           // one call site for the exact selection
+            const int c = c0 + lane;
+            sel.offer_key(c < total ? cand[wave][c] : kMaxKey, c < total);
+        }
+    } else {
+        // heavy ties at the cut: stream the row through the running selection instead
+        for (int j0 = 0; j0 < n4; j0 += 64) {
+            const int j4 = j0 + lane;
+            const bool valid = j4 < n4;
+            const float4 cur = row4[min(j4, n4 - 1)];
+            sel.template offer<false>(cur.x, (uint32_t)(4 * j4 + 0), valid);
+            sel.template offer<false>(cur.y, (uint32_t)(4 * j4 + 1), valid);
+            sel.template offer<false>(cur.z, (uint32_t)(4 * j4 + 2), valid);
+            sel.template offer<false>(cur.w, (uint32_t)(4 * j4 + 3), valid);
+        }
+    }
+    sel.flush();
+    if (lane < nprobe) {
+        const u64 key = sel.best[0];
+        const bool miss = key == kMaxKey;
+        cdis[q * nprobe + lane] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+        keys[q * nprobe + lane] = miss ? -1 : (int64_t)(uint32_t)key;
+    }
+}
+
 void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, float* cdis,
                           int64_t* keys, hipStream_t s) {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 3) / 4)), block(256);
-    if (nprobe <= 64)
+    if (nprobe <= 64 && (nlist & 3) == 0 && nlist >= 256 && nlist <= 8192) {
+        if (nlist <= 1024)
+            hipLaunchKernelGGL(coarse_select_reg_kernel<4>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+        else if (nlist <= 2048)
+            hipLaunchKernelGGL(coarse_select_reg_kernel<8>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+        else if (nlist <= 4096)
+            hipLaunchKernelGGL(coarse_select_reg_kernel<16>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+        else
+            hipLaunchKernelGGL(coarse_select_reg_kernel<32>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
+    } else if (nprobe <= 64)
         hipLaunchKernelGGL(coarse_select_kernel<1>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
     else if (nprobe <= 256)
         hipLaunchKernelGGL(coarse_select_kernel<4>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
