@@ -109,6 +109,27 @@ def test_coarse_ties_duplicate_centroids():
             assert np.array_equal(keys[i], rows[:nprobe])
 
 
+@pytest.mark.parametrize("nlist,nprobe", [(256, 1), (1000, 17), (2048, 64), (2052, 33), (5000, 32), (8192, 64), (8196, 8)])
+def test_coarse_select_row_sizes(nlist, nprobe):
+    """Every row-size class of the register-resident coarse select (and the streaming kernel just
+    outside its range) against the oracle's (distance, column) order, bit for bit."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(nlist + nprobe)
+    d, M = 16, 4
+    cent = rng.random((nlist, d)).astype(np.float32)
+    cent[nlist // 2:nlist // 2 + 40] = cent[3]              # a run of exact ties
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    xq = rng.random((50, d)).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, M, 8, cent, pq)
+    cd, keys = g.coarse_search(xq, nprobe)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+
+
 def test_coarse_small_batch_matches_reference(case):
     """< 20 queries: the reference takes the SSE path (no BLAS) -> bit-exact."""
     if case.n_small == 0:
