@@ -351,7 +351,7 @@ def main():
     if world == 1 and args.rank == 0 and not args.no_second_dataset:
         out["second_dataset"] = second_dataset(torch, args, dev)
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
         from oracle import pyoracle, refbench
         try:
             cores = len(os.sched_getaffinity(0))
