@@ -248,7 +248,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);   // query ordering is booked with the table stage
                 // run queries that share their nearest centroid next to each other (L2 reuse)
-                TRY(h->ws_hist.reserve(((size_t)h->nlist + 1) * sizeof(int)));
+                TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
                 TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,

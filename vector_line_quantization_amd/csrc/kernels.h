@@ -73,6 +73,13 @@ void launch_scan16w(const ScanArgs& a, int nw, hipStream_t s);
 bool scan16p_supports(const ScanArgs& a);
 void launch_scan16p(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
+// ints of scratch launch_query_order needs in `hist`: 2 x this
+inline size_t query_order_bins_padded(int nlist) {
+    int shift = 0;
+    while (((int64_t)nlist >> shift) > 16384) shift++;
+    const size_t nbins = (size_t)((((int64_t)nlist - 1) >> shift) + 2);
+    return (nbins + 63) & ~(size_t)63;
+}
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank = nullptr);

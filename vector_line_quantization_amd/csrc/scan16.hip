@@ -310,16 +310,21 @@ __global__ void qorder_hist_kernel(const int64_t* __restrict__ keys, int64_t nq,
     atomicAdd(&hist[ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1], 1);
 }
 
-__global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ hist, int nbins) {
-    __shared__ int part[1024];
+// prefix of the bin counts (every workgroup recomputes it in LDS: at most 16 Ki bins) + placement
+__global__ __launch_bounds__(256) void qorder_place_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
+                                                           int nlist, const int* __restrict__ hist,
+                                                           int* __restrict__ cnt, int* __restrict__ qorder,
+                                                           const int* __restrict__ list_rank, int shift, int nbins) {
+    extern __shared__ int pre[];                 // [nbins] exclusive prefix
+    __shared__ int part[256];
     const int t = threadIdx.x;
-    const int per = (nbins + 1023) / 1024;
+    const int per = (nbins + 255) / 256;
     const int b0 = t * per;
     int sum = 0;
     for (int i = 0; i < per; i++) if (b0 + i < nbins) sum += hist[b0 + i];
     part[t] = sum;
     __syncthreads();
-    for (int sft = 1; sft < 1024; sft <<= 1) {
+    for (int sft = 1; sft < 256; sft <<= 1) {
         const int v = t >= sft ? part[t - sft] : 0;
         __syncthreads();
         part[t] += v;
@@ -327,35 +332,33 @@ __global__ __launch_bounds__(1024) void qorder_scan_kernel(int* __restrict__ his
     }
     int run = part[t] - sum;
     for (int i = 0; i < per; i++)
-        if (b0 + i < nbins) { const int c = hist[b0 + i]; hist[b0 + i] = run; run += c; }
-}
-
-__global__ void qorder_scatter_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
-                                      int nlist, int* __restrict__ hist, int* __restrict__ qorder,
-                                      const int* __restrict__ list_rank, int shift, int nbins) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (b0 + i < nbins) { pre[b0 + i] = run; run += hist[b0 + i]; }
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * 256 + t;
     if (q >= nq) return;
     const int64_t k0 = keys[q * nprobe];
     const bool ok = k0 >= 0 && k0 < nlist;
-    const int pos = atomicAdd(&hist[ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1], 1);
-    qorder[pos] = (int)q;
+    const int bin = ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1;
+    qorder[pre[bin] + atomicAdd(&cnt[bin], 1)] = (int)q;
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank) {
     if (nq <= 0) return;
-    // at most 16 Ki bins (the prefix scan is one workgroup): many-list indexes are binned by the
-    // high bits of the list id / rank -- for a multi-index key that is its second sub-index
+    // at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
+    // by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
     int shift = 0;
     while (((int64_t)nlist >> shift) > 16384) shift++;
     const int nbins = (int)(((int64_t)nlist - 1) >> shift) + 2;        // last bin: invalid keys
-    (void)hipMemsetAsync(hist, 0, (size_t)nbins * sizeof(int), s);
+    const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
+    (void)hipMemsetAsync(hist, 0, 2 * stride * sizeof(int), s);
     const unsigned g = (unsigned)((nq + 255) / 256);
     hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank,
                        shift, nbins);
-    hipLaunchKernelGGL(qorder_scan_kernel, dim3(1), dim3(1024), 0, s, hist, nbins);
-    hipLaunchKernelGGL(qorder_scatter_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist,
-                       qorder, list_rank, shift, nbins);
+    const size_t smem = (size_t)nbins * sizeof(int);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
+    hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
+                       hist + stride, qorder, list_rank, shift, nbins);
 }
 
 }  // namespace vlq
