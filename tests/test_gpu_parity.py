@@ -130,6 +130,20 @@ def test_coarse_select_row_sizes(nlist, nprobe):
     assert np.array_equal(keys, keyso)
 
 
+@pytest.mark.parametrize("nq", [1, 3, 16, 100, 500])
+def test_small_batches_split_scan(nq):
+    """Serving-size batches: a query's probes are split over up to 8 workgroups and the partial rows
+    merged -- same distances, same labels, same tie order as the unsplit scan and the oracle."""
+    case = Case("c1_small")
+    g = gpu_index(case)
+    ox = case.oracle_index()
+    xq = np.concatenate([case.xq] * 8)[:nq]
+    for nprobe, k in ((64, 10), (8, 1), (33, 100), (64, 256)):
+        D, I = g.search(xq, nprobe, k)
+        Do, Io = ox.search(xq, nprobe, k, canonical=True)
+        assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io), (nprobe, k)
+
+
 def test_coarse_small_batch_matches_reference(case):
     """< 20 queries: the reference takes the SSE path (no BLAS) -> bit-exact."""
     if case.n_small == 0:

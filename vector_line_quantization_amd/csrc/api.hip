@@ -266,7 +266,24 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             else
 #endif
             if (h->ntotal < (int64_t)h->nlist * 24) vlq::launch_scan16_short(a, h->stream);   // a few codes per list
-            else vlq::launch_scan16(a, h->stream);
+            else {
+                // fewer workgroups than the chip holds (256 CUs x 4): split every query's probes over
+                // several workgroups and join the partial rows -- serving-size batches
+                int nsplit = 1;
+                while (k <= 256 && nsplit < 8 && ni * nsplit * 2 <= 1024 && nprobe / (nsplit * 2) >= 4) nsplit *= 2;
+                if (nsplit > 1) {
+                    TRY(h->ws_Dp.reserve((size_t)nsplit * ni * k * sizeof(float)));
+                    TRY(h->ws_Ip.reserve((size_t)nsplit * ni * k * sizeof(int64_t)));
+                    vlq::ScanArgs ap = a;
+                    ap.nsplit = nsplit;
+                    ap.D = h->ws_Dp.as<float>();
+                    ap.I = h->ws_Ip.as<int64_t>();
+                    vlq::launch_scan16(ap, h->stream);
+                    vlq::launch_merge_topk(ap.D, ap.I, ni, k, nsplit, a.D, a.I, h->stream);
+                } else {
+                    vlq::launch_scan16(a, h->stream);
+                }
+            }
             tm.stop();
         } else {
             StageTimer tm(h, 2);
@@ -361,7 +378,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
-                      &h->list_off, &h->list_len, &h->list_rank, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->list_off, &h->list_len, &h->list_rank, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats, &h->imi_cent,

@@ -43,12 +43,17 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     asm volatile("" : "+v"(two));   // keep the shift amount in a VGPR (SDWA takes no literal)
     // XCD-aware placement: hardware deals consecutive workgroups round-robin over the 8
     // XCDs, so give XCD x the x-th contiguous chunk of the (sorted) query order.
+    // small batches: a query's probes are split over a.nsplit workgroups (parts = contiguous ranges
+    // of the walking order) that write partial top-k rows [part][nq][k]; merge_topk_kernel joins them
     int64_t q;
+    int part = 0;
     {
         const int64_t b = blockIdx.x;
         const int64_t s = (b & 7) * a.xcd_chunk + (b >> 3);
-        if (s >= a.nq) return;
-        q = a.qorder ? a.qorder[s] : s;
+        if (s >= a.nq * a.nsplit) return;
+        const int64_t qs = s / a.nsplit;
+        part = (int)(s - qs * a.nsplit);
+        q = a.qorder ? a.qorder[qs] : qs;
     }
     const int64_t* kq = a.keys + q * a.nprobe;
 
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     float4 t2r[NI];
     uint4 c0 = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](int i) {     // i-th probe of the walking order
-        if (i >= nlive) return;
+        if (i >= nlive) return;      // (a part may look one probe past its range: harmless loads)
         const int p = ord[i];
         const int64_t key = pm.pkey[p];
         if (a.imi_nbits > 0) {
@@ -100,10 +105,11 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         if ((uint32_t)t < pm.plen[p])
             c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
     };
-    prefetch(0);
+    const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
+    prefetch(i_begin);
     int buf = 0;
     uint64_t nscan = 0;
-    for (int i = 0; i < nlive; i++) {
+    for (int i = i_begin; i < i_end; i++) {
         const int ik = ord[i];
         const uint32_t len = pm.plen[ik];
         const float dis0 = pm.pd0[ik];
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         if (NBUF == 2) buf ^= 1;
     }
 
-    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, q, wave, lane,
+    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                         [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
     if (badkey) *a.bad_key = 1;
@@ -277,7 +283,8 @@ static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipS
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     if (a_in.nq <= 0) return;
     ScanArgs a = a_in;
-    a.xcd_chunk = (int)((a.nq + 7) / 8);
+    if (a.nsplit < 1) a.nsplit = 1;
+    a.xcd_chunk = (int)((a.nq * a.nsplit + 7) / 8);
     // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
     // larger k keeps more selection state per wave, so stay at 4 waves
     // Measured alternatives (r01, MI355X, bench data): 8 waves per workgroup 0.95 ms, single
