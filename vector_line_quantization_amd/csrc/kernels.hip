@@ -908,6 +908,7 @@ void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, in
     dim3 grid((unsigned)((nq + 3) / 4)), block(256);
     if (k <= 64) hipLaunchKernelGGL(merge_topk_kernel<1>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
     else if (k <= 256) hipLaunchKernelGGL(merge_topk_kernel<4>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
+    else if (k <= 512) hipLaunchKernelGGL(merge_topk_kernel<8>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
     else hipLaunchKernelGGL(merge_topk_kernel<16>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
 }
 

@@ -299,6 +299,7 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     const size_t smem = lutb + tail;
     if (a.k <= 64) launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
     else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
+    else if (a.k <= 512) launch_scan16_t<8, 4, 2>(a, (int)lutb, smem, s);
     else launch_scan16_t<16, 4, 2>(a, (int)lutb, smem, s);
 }
 
