@@ -27,12 +27,13 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
     constexpr int NI = 16 / NW;       // float4 of the LUT per thread
+    constexpr int QR = KPL >= 8 ? 4 : 1;   // pending-queue capacity / 64 (wave_topk.cuh)
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [2][E]
     u64* queue = reinterpret_cast<u64*>(smraw + lut_region);              // [NW][64]
     ProbeMeta pm;
-    pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64), a.nprobe);
-    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) +
+    pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64 * QR), a.nprobe);
+    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64 * QR) +
                                                ProbeMeta::bytes(a.nprobe));    // cut, nlive
     uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
 
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     __syncthreads();
     const int nlive = misc[1];
 
-    WaveSelect<KPL> sel;
-    sel.init(a.k, queue + wave * 64, lane);
+    WaveSelect<KPL, QR> sel;
+    sel.init(a.k, queue + wave * 64 * QR, lane);
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         if (NBUF == 2) buf ^= 1;
     }
 
-    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
+    merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                         [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
     if (badkey) *a.bad_key = 1;
@@ -295,7 +296,7 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = (size_t)nw * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 64;
+    const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 64;
     const size_t smem = lutb + tail;
     if (a.k <= 64) launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
     else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);

@@ -94,10 +94,47 @@ __device__ __forceinline__ void wave_bitonic_merge(u64 (&best)[KPL], int lane) {
     }
 }
 
+// Ascending bitonic sort of N = 64*R keys (element e = r*64 + lane).
+template <int R>
+__device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
+    if (R == 1) { p[0] = wave_sort64(p[0], lane); return; }
+#pragma unroll
+    for (int size = 2; size <= 64 * R; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {                 // partner in another register, same lane
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((r & rs) == 0) {
+                        const bool up = (((r * 64) & size) == 0) || size == 64 * R;
+                        const u64 a = p[r], b = p[r | rs];
+                        p[r] = up ? umin64(a, b) : umax64(a, b);
+                        p[r | rs] = up ? umax64(a, b) : umin64(a, b);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const u64 other = shfl_xor_u64(p[r], stride);
+                    const int e = r * 64 + lane;
+                    const bool up = ((e & size) == 0) || size == 64 * R;
+                    const bool lower = (lane & stride) == 0;
+                    p[r] = (lower == up) ? umin64(p[r], other) : umax64(p[r], other);
+                }
+            }
+        }
+    }
+}
+
 // Running selection state of one wave.  `queue` = 64 u64 slots of LDS owned by
 // this wave.
-template <int KPL>
+// QR = pending-queue capacity in units of 64 keys (LDS: 64*QR u64 per wave).  A flush costs one
+// sort of the pending keys plus one merge of the whole best list, so long lists (KPL >= 8) want
+// QR = 4: four times fewer merges of 512..1024 keys.
+template <int KPL, int QR = 1>
 struct WaveSelect {
+    static_assert(QR <= KPL, "the pending queue cannot exceed the best list");
     u64 best[KPL];
     float thr;        // admission threshold (distance of the k-th best, or FLT_MAX)
     int npend;        // entries parked in `queue` (wave-uniform)
@@ -129,10 +166,16 @@ struct WaveSelect {
     // merge the parked candidates into the best list
     __device__ __forceinline__ void flush() {
         if (npend == 0) return;
-        u64 p = (lane < npend) ? queue[lane] : kMaxKey;
-        p = wave_sort64(p, lane);
-        u64 rev = shfl_u64(p, 63 - lane);
-        best[KPL - 1] = umin64(best[KPL - 1], rev);
+        u64 p[QR];
+#pragma unroll
+        for (int r = 0; r < QR; r++) p[r] = (r * 64 + lane < npend) ? queue[r * 64 + lane] : kMaxKey;
+        wave_sort_multi<QR>(p, lane);
+        // pending reversed (element e -> N-1-e) against the tail of the best list: bitonic split
+#pragma unroll
+        for (int r = 0; r < QR; r++) {
+            const u64 rev = shfl_u64(p[QR - 1 - r], 63 - lane);
+            best[KPL - QR + r] = umin64(best[KPL - QR + r], rev);
+        }
         wave_bitonic_merge<KPL>(best, lane);
         npend = 0;
         update_threshold();
@@ -150,7 +193,7 @@ struct WaveSelect {
         u64 mask = __ballot(pred);
         if (mask == 0) return;
         int c = __popcll(mask);
-        if (npend + c > 64) {
+        if (npend + c > 64 * QR) {
             flush();
             pred = pred && (ORDERED ? dis < thr : dis <= thr);
             mask = __ballot(pred);
@@ -170,7 +213,7 @@ struct WaveSelect {
         u64 mask = __ballot(pred);
         if (mask == 0) return;
         int c = __popcll(mask);
-        if (npend + c > 64) flush();
+        if (npend + c > 64 * QR) flush();
         if (pred) {
             int slot = npend + __popcll(mask & ((1ull << lane) - 1ull));
             queue[slot] = key;
