@@ -40,7 +40,7 @@ hipEvent_t get_event(vlq_ivfpq_t h) {
 struct StageTimer {
     vlq_ivfpq_t h; int stage; hipEvent_t a = nullptr, b = nullptr;
     StageTimer(vlq_ivfpq_t h_, int stage_) : h(h_), stage(stage_) {
-        if (!h->prof) return;
+        if (!h->prof || (h->prof_scan_only && stage != 2)) return;
         a = get_event(h); b = get_event(h);
         if (a) (void)hipEventRecord(a, h->stream);
     }
@@ -712,6 +712,7 @@ int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
 int vlq_ivfpq_profile(vlq_ivfpq_t h, int enable) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     h->prof = enable != 0;
+    h->prof_scan_only = enable == 2;
     return VLQ_OK;
 }
 

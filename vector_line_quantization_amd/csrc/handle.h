@@ -105,7 +105,7 @@ struct vlq_ivfpq_s {
     uint64_t stat_nq = 0;
 
     // profiling
-    bool prof = false;
+    bool prof = false, prof_scan_only = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     struct Pending { hipEvent_t a, b; int stage; };
     std::vector<Pending> pending;
