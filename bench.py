@@ -296,9 +296,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the gathered copy of this rank's slice is this rank's result
-        assert torch.equal(Dall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], D)
-        assert torch.equal(Iall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], I)
+        # the gathered copy of this rank's slice is this rank's result (reported, not asserted)
+        gather_ok = bool(torch.equal(Dall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], D) and
+                         torch.equal(Iall[(nstep[0] - 1) & 1][rank * args.nq:(rank + 1) * args.nq], I))
+    else:
+        gather_ok = None
 
     if rank != 0:
         if use_dist:
@@ -343,6 +345,7 @@ def main():
                      "scan": prof_all["scan_ms"] / 5, "note": "from 5 extra untimed steps with every stage instrumented"},
     }
 
+    out["config"]["all_gather_check"] = gather_ok
     # ---- parity spot check + recall + CPU baseline (outside the timed region) ----
     ox = oracle_copy(g, args, coarse, pq)
     xq_h = xq.cpu().numpy()
