@@ -346,108 +346,114 @@ def main():
     }
 
     out["config"]["all_gather_check"] = gather_ok
-    # ---- parity spot check + recall + CPU baseline (outside the timed region) ----
-    ox = oracle_copy(g, args, coarse, pq)
-    xq_h = xq.cpu().numpy()
-    D_h, I_h = D.cpu().numpy(), I.cpu().numpy()
-    nchk = min(512, args.nq)
-    Do, Io = ox.search(xq_h[:nchk], args.nprobe, args.k, canonical=True)
-    out["parity"] = {"queries_checked": nchk,
-                     "distance_bits_equal": bool(np.array_equal(D_h[:nchk].view(np.uint32), Do.view(np.uint32))),
-                     "label_mismatches": int((I_h[:nchk] != Io).sum())}
-    r1, r10 = recall(torch, xq, xb, I_h, args.nb, dev)
-    out["config"]["recall_at_1"] = r1
-    out["config"]["recall_1_at_10"] = r10
-    if world == 1 and args.rank == 0 and not args.no_second_dataset:
-        out["second_dataset"] = second_dataset(torch, args, dev)
+    # everything below is outside the timed region; a failure there must not lose the measured line
+    try:
+        # ---- parity spot check + recall + CPU baseline (outside the timed region) ----
+        ox = oracle_copy(g, args, coarse, pq)
+        xq_h = xq.cpu().numpy()
+        D_h, I_h = D.cpu().numpy(), I.cpu().numpy()
+        nchk = min(512, args.nq)
+        Do, Io = ox.search(xq_h[:nchk], args.nprobe, args.k, canonical=True)
+        out["parity"] = {"queries_checked": nchk,
+                         "distance_bits_equal": bool(np.array_equal(D_h[:nchk].view(np.uint32), Do.view(np.uint32))),
+                         "label_mismatches": int((I_h[:nchk] != Io).sum())}
+        r1, r10 = recall(torch, xq, xb, I_h, args.nb, dev)
+        out["config"]["recall_at_1"] = r1
+        out["config"]["recall_1_at_10"] = r10
+        if world == 1 and args.rank == 0 and not args.no_second_dataset:
+            out["second_dataset"] = second_dataset(torch, args, dev)
 
-    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
-        from oracle import pyoracle, refbench
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count()
-        ncpu = min(args.cpu_queries, args.nq)
-        cand_threads = sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)})
-        done = False
-        if refbench.available():
-            # the REFERENCE's own CPU IndexIVFPQ (oracle/_ref, compiled from the reference's sources by
-            # oracle/ref.mk) on this box's host cores: same index (handed over in the reference's file
-            # format), same queries, same nprobe / k
-            import tempfile
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
+            from oracle import pyoracle, refbench
             try:
-                with tempfile.TemporaryDirectory() as td:
-                    ipath = os.path.join(td, "bench.faissindex")
-                    refbench.write_ivfpq_index(ipath, ox.coarse_centroids,
-                                               pq.cpu().numpy(), 8, ox.codes, ox.ids, ox.list_offsets)
-                    best_t, best_dt = cand_threads[0], float("inf")
-                    for nt in cand_threads:                       # thread count that serves this host best
-                        _d, _i, secs, _m = refbench.run_reference(ipath, xq_h[:min(ncpu, 2000)], args.nprobe, args.k, 1, nt)
-                        if secs[0] < best_dt:
-                            best_t, best_dt = nt, float(secs[0])
-                    Dr, Ir, secs, meta = refbench.run_reference(ipath, xq_h[:ncpu], args.nprobe, args.k, 3, best_t)
-                med = float(np.sort(secs)[1])
-                out["cpu_baseline"] = {"value": ncpu / med, "unit": "queries/s", "cores": int(meta[2]), "kind": "reference",
-                                       "sample": "%d of the same queries, same index (reference file format), median of 3 "
-                                                 "IndexIVFPQ::search calls of the compiled reference (oracle/_ref, MKL), "
-                                                 "%d OpenMP threads = fastest of %s tried; affinity mask %d cpus, host %d "
-                                                 "logical cpus; use_precomputed_table=%d, ncode/query=%.0f"
-                                                 % (ncpu, int(meta[2]), cand_threads, cores, os.cpu_count(), int(meta[0]),
-                                                    float(meta[1]) / ncpu)}
-                # the reference's answers beside the MI355X's, all sampled queries: labels up to exact-distance
-                # ties and the BLAS coarse stage's rounding, distances to 1e-4 relative
-                Dg, Ig = D_h[:ncpu], I_h[:ncpu]
-                same = Ig == Ir
-                rel = np.abs(Dg[same] - Dr[same]) / np.maximum(np.abs(Dr[same]), 1e-20)
-                # labels inside a group of bit-equal distances may come in any order, and a group cut by
-                # the k-th place may keep different members (the reference's heap history decides, SURVEY.md
-                # section 7): compare groups as sets, groups reaching the last place by distance only
-                slots_ok = 0
-                for r in range(ncpu):
-                    a = 0
-                    while a < args.k:
-                        b = a + 1
-                        while b < args.k and Dr[r, b] == Dr[r, a]:
-                            b += 1
-                        if np.array_equal(Dg[r, a:b].view(np.uint32), Dr[r, a:b].view(np.uint32)):
-                            if b == args.k:
-                                slots_ok += b - a
-                            else:
-                                slots_ok += len(set(Ig[r, a:b].tolist()) & set(Ir[r, a:b].tolist()))
-                        a = b
-                out["parity"]["vs_reference_cpu"] = {
-                    "queries": int(ncpu), "labels_equal_slot_by_slot": float(same.mean()),
-                    "labels_equal_up_to_exact_distance_ties": slots_ok / float(ncpu * args.k),
-                    "distance_bits_equal_frac": float((Dg.view(np.uint32) == Dr.view(np.uint32)).mean()),
-                    "max_rel_distance_error_on_equal_labels": float(rel.max()) if rel.size else 0.0}
-                done = True
-            except Exception as e:     # no MKL on this host, driver failure: fall back to the port, say so
-                out["cpu_baseline_note"] = "reference run failed (%s); port timed instead" % (str(e)[:200],)
-        if not done:
-            # pick the OpenMP thread count that serves the CPU best on this box (the affinity mask
-            # can be wider than the container's cpu share)
-            best_t, best_dt = 1, float("inf")
-            for nt in cand_threads:
-                pyoracle.set_num_threads(nt)
-                ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
-                t1 = time.perf_counter()
-                ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
-                dt = time.perf_counter() - t1
-                if dt < best_dt:
-                    best_t, best_dt = nt, dt
-            pyoracle.set_num_threads(best_t)
-            ts = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                ox.search(xq_h[:ncpu], args.nprobe, args.k)
-                ts.append(time.perf_counter() - t1)
-            ts.sort()
-            out["cpu_baseline"] = {"value": ncpu / ts[1], "unit": "queries/s", "cores": pyoracle.num_threads(),
-                                   "kind": "port",
-                                   "sample": "%d of the same queries, same index, median of 3 search() calls, "
-                                             "oracle restatement (-O3 -fopenmp, %d OpenMP threads = fastest of "
-                                             "8..%d tried; affinity mask %d cpus, host %d logical cpus)"
-                                             % (ncpu, pyoracle.num_threads(), cores, cores, os.cpu_count())}
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count()
+            ncpu = min(args.cpu_queries, args.nq)
+            cand_threads = sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256)})
+            done = False
+            if refbench.available():
+                # the REFERENCE's own CPU IndexIVFPQ (oracle/_ref, compiled from the reference's sources by
+                # oracle/ref.mk) on this box's host cores: same index (handed over in the reference's file
+                # format), same queries, same nprobe / k
+                import tempfile
+                try:
+                    with tempfile.TemporaryDirectory() as td:
+                        ipath = os.path.join(td, "bench.faissindex")
+                        refbench.write_ivfpq_index(ipath, ox.coarse_centroids,
+                                                   pq.cpu().numpy(), 8, ox.codes, ox.ids, ox.list_offsets)
+                        best_t, best_dt = cand_threads[0], float("inf")
+                        for nt in cand_threads:                       # thread count that serves this host best
+                            _d, _i, secs, _m = refbench.run_reference(ipath, xq_h[:min(ncpu, 2000)], args.nprobe, args.k, 1, nt)
+                            if secs[0] < best_dt:
+                                best_t, best_dt = nt, float(secs[0])
+                        Dr, Ir, secs, meta = refbench.run_reference(ipath, xq_h[:ncpu], args.nprobe, args.k, 3, best_t)
+                    med = float(np.sort(secs)[1])
+                    out["cpu_baseline"] = {"value": ncpu / med, "unit": "queries/s", "cores": int(meta[2]), "kind": "reference",
+                                           "sample": "%d of the same queries, same index (reference file format), median of 3 "
+                                                     "IndexIVFPQ::search calls of the compiled reference (oracle/_ref, MKL), "
+                                                     "%d OpenMP threads = fastest of %s tried; affinity mask %d cpus, host %d "
+                                                     "logical cpus; use_precomputed_table=%d, ncode/query=%.0f"
+                                                     % (ncpu, int(meta[2]), cand_threads, cores, os.cpu_count(), int(meta[0]),
+                                                        float(meta[1]) / ncpu)}
+                    # the reference's answers beside the MI355X's, all sampled queries: labels up to exact-distance
+                    # ties and the BLAS coarse stage's rounding, distances to 1e-4 relative
+                    Dg, Ig = D_h[:ncpu], I_h[:ncpu]
+                    same = Ig == Ir
+                    rel = np.abs(Dg[same] - Dr[same]) / np.maximum(np.abs(Dr[same]), 1e-20)
+                    # labels inside a group of bit-equal distances may come in any order, and a group cut by
+                    # the k-th place may keep different members (the reference's heap history decides, SURVEY.md
+                    # section 7): compare groups as sets, groups reaching the last place by distance only
+                    slots_ok = 0
+                    for r in range(ncpu):
+                        a = 0
+                        while a < args.k:
+                            b = a + 1
+                            while b < args.k and Dr[r, b] == Dr[r, a]:
+                                b += 1
+                            if np.array_equal(Dg[r, a:b].view(np.uint32), Dr[r, a:b].view(np.uint32)):
+                                if b == args.k:
+                                    slots_ok += b - a
+                                else:
+                                    slots_ok += len(set(Ig[r, a:b].tolist()) & set(Ir[r, a:b].tolist()))
+                            a = b
+                    out["parity"]["vs_reference_cpu"] = {
+                        "queries": int(ncpu), "labels_equal_slot_by_slot": float(same.mean()),
+                        "labels_equal_up_to_exact_distance_ties": slots_ok / float(ncpu * args.k),
+                        "distance_bits_equal_frac": float((Dg.view(np.uint32) == Dr.view(np.uint32)).mean()),
+                        "max_rel_distance_error_on_equal_labels": float(rel.max()) if rel.size else 0.0}
+                    done = True
+                except Exception as e:     # no MKL on this host, driver failure: fall back to the port, say so
+                    out["cpu_baseline_note"] = "reference run failed (%s); port timed instead" % (str(e)[:200],)
+            if not done:
+                # pick the OpenMP thread count that serves the CPU best on this box (the affinity mask
+                # can be wider than the container's cpu share)
+                best_t, best_dt = 1, float("inf")
+                for nt in cand_threads:
+                    pyoracle.set_num_threads(nt)
+                    ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
+                    t1 = time.perf_counter()
+                    ox.search(xq_h[:min(ncpu, 2000)], args.nprobe, args.k)
+                    dt = time.perf_counter() - t1
+                    if dt < best_dt:
+                        best_t, best_dt = nt, dt
+                pyoracle.set_num_threads(best_t)
+                ts = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ox.search(xq_h[:ncpu], args.nprobe, args.k)
+                    ts.append(time.perf_counter() - t1)
+                ts.sort()
+                out["cpu_baseline"] = {"value": ncpu / ts[1], "unit": "queries/s", "cores": pyoracle.num_threads(),
+                                       "kind": "port",
+                                       "sample": "%d of the same queries, same index, median of 3 search() calls, "
+                                                 "oracle restatement (-O3 -fopenmp, %d OpenMP threads = fastest of "
+                                                 "8..%d tried; affinity mask %d cpus, host %d logical cpus)"
+                                                 % (ncpu, pyoracle.num_threads(), cores, cores, os.cpu_count())}
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+        out["post_run_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        traceback.print_exc(file=sys.stderr)
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
