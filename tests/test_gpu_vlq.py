@@ -148,3 +148,35 @@ def test_error_paths(world):
         vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, v.nlist, 16)     # nedge >= nlist
     with pytest.raises(vlq.VlqError):
         vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, 4, 300)          # lambda index does not fit a byte
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_vlq_configuration(seed):
+    """Seeded random VLQ shapes (generic and 16-byte scan kernels, device-side add in batches,
+    empty and over-long lines, w1 / k on both sides of the selection widths) against the oracle."""
+    rng = np.random.default_rng(500 + seed)
+    M = int(rng.choice([2, 4, 8, 16, 16]))
+    nbits = 8 if M == 16 else int(rng.choice([4, 6, 8]))
+    dsub = int(rng.choice([2, 4, 6, 8]))
+    nlist = int(rng.choice([6, 20, 64]))
+    nedge = int(rng.choice([1, 2, 5]))
+    nedge = min(nedge, nlist - 1)
+    nlambda = int(rng.choice([4, 32, 256]))
+    nb = int(rng.choice([50, 1500, 6000]))
+    v, xb, xq = make_vlq(seed=600 + seed, d=M * dsub, nlist=nlist, M=M, nbits=nbits, nedge=nedge, nlambda=nlambda, nb=nb)
+    g = gpu_from_oracle(v, with_lists=False)
+    cut = nb // 3
+    g.add(xb[:cut])
+    g.add(xb[cut:])
+    assert g.ntotal == nb
+    for line in range(nlist * nedge):
+        c, lam, ids = g.get_list(line)
+        o0, o1 = v.line_off[line], v.line_off[line + 1]
+        assert np.array_equal(ids, v.ids[o0:o1]) and np.array_equal(c, v.codes[o0:o1]) and np.array_equal(lam, v.lambdas[o0:o1])
+    nprobe = int(rng.choice([1, 4, nlist]))
+    w1 = int(rng.choice([1, 7, 64, 65, 300]))
+    k = int(rng.choice([1, 10, 64, 65, 257]))
+    D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
+    Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
