@@ -193,8 +193,13 @@ class GpuIndexIVFPQ : public GpuIndex {
   int getNumProbes() const { return nprobe_; }
 
   void reset() override {
-    std::vector<int64_t> off(nlist_ + 1, 0);
-    VLQ_CHECK(vlq_ivfpq_set_lists(h_, nullptr, nullptr, off.data()));
+    if (line_) {       // VLQ index: the lists are the lines
+      std::vector<int64_t> off((size_t)nlist_ * numedge_ + 1, 0);
+      VLQ_CHECK(vlq_line_set_lists(line_, nullptr, nullptr, nullptr, off.data()));
+    } else if (h_) {
+      std::vector<int64_t> off(nlist_ + 1, 0);
+      VLQ_CHECK(vlq_ivfpq_set_lists(h_, nullptr, nullptr, off.data()));
+    }
     ntotal = 0;
   }
 

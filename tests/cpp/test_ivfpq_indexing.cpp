@@ -106,6 +106,18 @@ int main() {
            v_ok, nq, (int)(nq * 0.3), vlqIndex.ntotal, vlqIndex.edgeInfo_[0], vlqIndex.edgeDistInfo_[0], vlqIndex.lambdaInfo_[0]);
     EXPECT(v_ok > nq * 0.3);
     EXPECT(vlqIndex.isVLQ() && vlqIndex.ntotal == (faiss::Index::idx_t)nb);
+    {   // reset() empties the lines; adding again gives the same answers
+      std::vector<faiss::Index::idx_t> n0((size_t)k * nq);
+      std::vector<float> d0((size_t)k * nq);
+      vlqIndex.search(nq, queries.data(), k, d0.data(), n0.data());
+      vlqIndex.reset();
+      EXPECT(vlqIndex.ntotal == 0);
+      vlqIndex.add(nb, database.data());
+      std::vector<faiss::Index::idx_t> n1((size_t)k * nq);
+      std::vector<float> d1((size_t)k * nq);
+      vlqIndex.search(nq, queries.data(), k, d1.data(), n1.data());
+      EXPECT(n0 == n1 && d0 == d1);
+    }
     // the fork's raw files: a second index loaded from .ppqt/.db* answers identically, and
     // two list-range shards (readDbFromFile(name, 2, r)) merged with merge() do too
     vlqIndex.writeCodebookToFile("/tmp/vlq_test");
