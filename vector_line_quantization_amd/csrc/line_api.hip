@@ -278,6 +278,7 @@ int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambda
     h->h_line_off.swap(off);
     h->h_line_len.swap(len);
     h->ntotal = nt;
+    h->ntotal_added = nt;        // sequential ids continue from the loaded count (IndexIVFPQ.cpp:244)
     return VLQ_OK;
 }
 
