@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
-    uint4 c0 = make_uint4(0, 0, 0, 0);
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
     auto prefetch = [&](int i) {     // i-th probe of the walking order
         if (i >= nlive) return;      // (a part may look one probe past its range: harmless loads)
         const int p = ord[i];
@@ -103,8 +103,12 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
         }
-        if ((uint32_t)t < pm.plen[p])
-            c0 = reinterpret_cast<const uint4*>(a.codes)[pm.poff[p] + t];
+        {   // this thread's first two codes of the list, clamped (branch-free loads)
+            const uint4* cpn = reinterpret_cast<const uint4*>(a.codes) + pm.poff[p];
+            const uint32_t last = pm.plen[p] - 1;
+            c0 = cpn[min((uint32_t)t, last)];
+            c1 = cpn[min((uint32_t)t + NT, last)];
+        }
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
     prefetch(i_begin);
@@ -119,17 +123,48 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         float* L = lut + buf * E;
         if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
         build_lut16<NI>(L, t, t2r, m2t3);
-        uint4 cc = c0;
+        uint4 cc = c0, cd = c1;
         prefetch(i + 1);
         __syncthreads();
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;
-#pragma unroll 2
-            for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
+            uint32_t j0 = (uint32_t)wave * 64;
+            // two chunks per trip in four half blocks of 8 lookups: while the 8 dependent adds of one
+            // half block run, the next half block's reads are in flight (counted lgkmcnt) -- LDS and
+            // VALU overlap inside a wave instead of only between waves
+            for (; j0 + NT < len; j0 += 2 * NT) {
+                const uint32_t ja = j0 + lane, jb = ja + NT;
+                const uint4 ca = cc, cb = cd;
+                cc = cp[min(jb + NT, len - 1)];              // the next trip's two chunks
+                cd = cp[min(jb + 2 * NT, len - 1)];
+                float h1[8], h2[8], h3[8], h4[8];
+                if (B == 0) { { float (&v)[8] = h1; VLQ_G8LO_NW(0, ca.x, ca.y); } { float (&v)[8] = h2; VLQ_G8HI_NW(0, ca.z, ca.w); } }
+                else { { float (&v)[8] = h1; VLQ_G8LO_NW(16384, ca.x, ca.y); } { float (&v)[8] = h2; VLQ_G8HI_NW(16384, ca.z, ca.w); } }
+                VLQ_WAIT8(8, h1);
+                float da = dis0;
+#pragma unroll
+                for (int m = 0; m < 8; m++) da = __fadd_rn(da, h1[m]);
+                asm volatile("" : "+v"(da));
+                if (B == 0) { float (&v)[8] = h3; VLQ_G8LO_NW(0, cb.x, cb.y); } else { float (&v)[8] = h3; VLQ_G8LO_NW(16384, cb.x, cb.y); }
+                VLQ_WAIT8(8, h2);
+#pragma unroll
+                for (int m = 0; m < 8; m++) da = __fadd_rn(da, h2[m]);
+                asm volatile("" : "+v"(da));
+                if (B == 0) { float (&v)[8] = h4; VLQ_G8HI_NW(0, cb.z, cb.w); } else { float (&v)[8] = h4; VLQ_G8HI_NW(16384, cb.z, cb.w); }
+                sel.offer(da, pos0 + ja, true);          // chunk A's selection while chunk B's reads are in flight
+                VLQ_WAIT8(8, h3);
+                float db = dis0;
+#pragma unroll
+                for (int m = 0; m < 8; m++) db = __fadd_rn(db, h3[m]);
+                asm volatile("" : "+v"(db));
+                VLQ_WAIT8(0, h4);
+#pragma unroll
+                for (int m = 0; m < 8; m++) db = __fadd_rn(db, h4[m]);
+                sel.offer(db, pos0 + jb, jb < len);
+            }
+            for (; j0 < len; j0 += NT) {
                 const uint32_t j = j0 + lane;
-                // next chunk, clamped instead of predicated: a branch-free load (lanes past the
-                // end re-read the last code and are masked out of the selection)
                 const uint4 cn = cp[min(j + NT, len - 1)];
                 const float dis = adc16_fixed<B>(cc, dis0, two);
                 sel.offer(dis, pos0 + j, j < len);

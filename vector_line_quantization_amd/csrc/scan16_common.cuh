@@ -120,6 +120,56 @@ __device__ __forceinline__ float adc16(const float* L, const uint4 cc, float dis
         : "v"(cc.x), "v"(cc.y), "v"(cc.z), "v"(cc.w), "v"(two)                                       \
         : "memory")
 
+// Half blocks of VLQ_G16_ASM (sub-quantizers 0-7 from code words x,y; 8-15 from z,w) WITHOUT the
+// trailing wait, and a counted wait: lgkmcnt is a 4-bit counter, so a wave can have 16 LDS reads in
+// flight -- two half blocks.  The list loop keeps one half block in flight while it adds the other.
+#define VLQ_G8LO_NW(O, W0, W1)                                                                   \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:" #O "+0\n\t" \
+        "ds_read_b32 %1, %1 offset:" #O "+1024\n\t" \
+        "ds_read_b32 %2, %2 offset:" #O "+2048\n\t" \
+        "ds_read_b32 %3, %3 offset:" #O "+3072\n\t" \
+        "ds_read_b32 %4, %4 offset:" #O "+4096\n\t" \
+        "ds_read_b32 %5, %5 offset:" #O "+5120\n\t" \
+        "ds_read_b32 %6, %6 offset:" #O "+6144\n\t" \
+        "ds_read_b32 %7, %7 offset:" #O "+7168"                                                                                 \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two)                                                       \
+        : "memory")
+#define VLQ_G8HI_NW(O, W0, W1)                                                                   \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:" #O "+8192\n\t" \
+        "ds_read_b32 %1, %1 offset:" #O "+9216\n\t" \
+        "ds_read_b32 %2, %2 offset:" #O "+10240\n\t" \
+        "ds_read_b32 %3, %3 offset:" #O "+11264\n\t" \
+        "ds_read_b32 %4, %4 offset:" #O "+12288\n\t" \
+        "ds_read_b32 %5, %5 offset:" #O "+13312\n\t" \
+        "ds_read_b32 %6, %6 offset:" #O "+14336\n\t" \
+        "ds_read_b32 %7, %7 offset:" #O "+15360"                                                                                 \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two)                                                       \
+        : "memory")
+#define VLQ_WAIT8(N, v)                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                        \
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) \
+                 :: "memory")
+
 template <int BUF>
 __device__ __forceinline__ float adc16_fixed(const uint4 cc, float dis, uint32_t two) {
     float v[16];
