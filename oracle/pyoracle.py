@@ -41,6 +41,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        # a test box may expose 256 logical CPUs and grant a fraction of them: 256 spinning OpenMP
+        # threads on 16 granted cores turn a 1-second encode into minutes.  Callers that time the
+        # oracle (bench.py) set the thread count themselves (set_num_threads).
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(_SO)
         L.orc_fvec_inner_product.restype = C.c_float
         L.orc_fvec_norm_L2sqr.restype = C.c_float
@@ -49,6 +53,12 @@ def lib():
         L.orc_search.restype = C.c_int64
         L.orc_num_threads.restype = C.c_int
         L.orc_vlq_search.restype = C.c_int64
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                granted = len(os.sched_getaffinity(0))
+            except AttributeError:
+                granted = os.cpu_count() or 1
+            L.orc_set_num_threads(C.c_int(max(1, min(16, granted))))
         _lib = L
     return _lib
 

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
             // two chunks per trip in four half blocks of 8 lookups: while the 8 dependent adds of one
             // half block run, the next half block's reads are in flight (counted lgkmcnt) -- LDS and
             // VALU overlap inside a wave instead of only between waves
-            for (; j0 + NT < len; j0 += 2 * NT) {
+            // (only with one key per lane: the 32 extra registers cost the longer selections a wave of
+            // occupancy, measured k = 100: 1.27 -> 1.47 ms)
+            for (; KPL == 1 && j0 + NT < len; j0 += 2 * NT) {
                 const uint32_t ja = j0 + lane, jb = ja + NT;
                 const uint4 ca = cc, cb = cd;
                 cc = cp[min(jb + NT, len - 1)];              // the next trip's two chunks
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
                 for (int m = 0; m < 8; m++) da = __fadd_rn(da, h2[m]);
                 asm volatile("" : "+v"(da));
                 if (B == 0) { float (&v)[8] = h4; VLQ_G8HI_NW(0, cb.z, cb.w); } else { float (&v)[8] = h4; VLQ_G8HI_NW(16384, cb.z, cb.w); }
-                sel.offer(da, pos0 + ja, true);          // chunk A's selection while chunk B's reads are in flight
+                // chunk A's admission test while chunk B's reads are in flight; the (rare) insertion itself
+                // waits until nothing is in flight: no control flow between an LDS read and its wait
+                const bool hit_a = __builtin_amdgcn_ballot_w64(da < sel.thr) != 0;
                 VLQ_WAIT8(8, h3);
                 float db = dis0;
 #pragma unroll
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
                 VLQ_WAIT8(0, h4);
 #pragma unroll
                 for (int m = 0; m < 8; m++) db = __fadd_rn(db, h4[m]);
+                if (hit_a) sel.offer(da, pos0 + ja, true);
                 sel.offer(db, pos0 + jb, jb < len);
             }
             for (; j0 < len; j0 += NT) {
