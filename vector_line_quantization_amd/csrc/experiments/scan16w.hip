@@ -183,33 +183,32 @@ __global__ __launch_bounds__(64 * NW) void scan16w_kernel(ScanArgs a) {
         // one copy of the list loop per wave: the LUT's LDS offset is an immediate
         auto scan_list = [&](auto wc) {
             constexpr int W = decltype(wc)::value;
+            // half-block software pipeline (adc16_pipeline) over up to PD chunks per trip
             for (uint32_t i0 = 0; i0 < nchunk; i0 += PD) {
+                uint4 c[PD];
+#pragma unroll
+                for (int u = 0; u < PD; u++) {
+                    c[u] = cq[u];
+                    cq[u] = cp[min((i0 + u + PD) * 64 + lane, len - 1)];       // chunks PD ahead, clamped, unconditional
+                }
+                const uint32_t left = nchunk - i0;
+                float acc[PD];
+                if (left >= PD) {
+                    adc16_pipeline<PD, W * 16384>(c, dis0, two, acc);
+                } else if (left >= 2) {
+                    const uint4 c2[2] = {c[0], c[1]};
+                    float a2[2];
+                    adc16_pipeline<2, W * 16384>(c2, dis0, two, a2);
+                    acc[0] = a2[0]; acc[1] = a2[1];
+                    if (left == 3) acc[2] = adc16_wave<W>(c[2], dis0, two);
+                } else {
+                    acc[0] = adc16_wave<W>(c[0], dis0, two);
+                }
 #pragma unroll
                 for (int u = 0; u < PD; u++) {
                     const uint32_t j = (i0 + u) * 64 + lane;
-                    if (i0 + u < nchunk) {                 // wave-uniform
-#ifdef VLQ_STAMPS
-                        const unsigned long long x0 = STAMP();
-                        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                        const unsigned long long x1 = STAMP();
-                        float dis = adc16_wave<W>(cq[u], dis0, two);
-                        asm volatile("" : "+v"(dis));
-                        const unsigned long long x2 = STAMP();
-                        sel.offer(dis, pos0 + j, j < len);
-                        const unsigned long long x3 = STAMP();
-                        s_x[0] += x1 - x0; s_x[1] += x2 - x1; s_x[2] += x3 - x2;
-#elif defined(VLQ_ABL) && (VLQ_ABL & 1)
-                        const float dis = __fadd_rn(dis0, __uint_as_float((cq[u].x ^ cq[u].y ^ cq[u].z ^ cq[u].w) & 0x3fffffffu));
-                        sel.offer(dis, pos0 + j, j < len);
-#else
-                        const float dis = adc16_wave<W>(cq[u], dis0, two);
-                        sel.offer(dis, pos0 + j, j < len);
-#endif
-                    }
-                    // chunk PD ahead into the registers just consumed; clamped, unconditional
-#if !(defined(VLQ_ABL) && (VLQ_ABL & 4))
-                    cq[u] = cp[min(j + 64 * PD, len - 1)];
-#endif
+                    const bool in = (uint32_t)u < left && j < len;
+                    if (__builtin_amdgcn_ballot_w64(in && acc[u] < sel.thr)) sel.offer(acc[u], pos0 + j, in);
                 }
             }
         };

@@ -170,6 +170,76 @@ __device__ __forceinline__ float adc16(const float* L, const uint4 cc, float dis
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) \
                  :: "memory")
 
+// the same half blocks with the LUT offset as a compile-time operand (template parameters)
+#define VLQ_G8LO_NWI(OFFS, W0, W1)                                                                \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:%11+0\n\t" \
+        "ds_read_b32 %1, %1 offset:%11+1024\n\t" \
+        "ds_read_b32 %2, %2 offset:%11+2048\n\t" \
+        "ds_read_b32 %3, %3 offset:%11+3072\n\t" \
+        "ds_read_b32 %4, %4 offset:%11+4096\n\t" \
+        "ds_read_b32 %5, %5 offset:%11+5120\n\t" \
+        "ds_read_b32 %6, %6 offset:%11+6144\n\t" \
+        "ds_read_b32 %7, %7 offset:%11+7168"                                                                                 \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two), "n"(OFFS)                                            \
+        : "memory")
+#define VLQ_G8HI_NWI(OFFS, W0, W1)                                                                \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:%11+8192\n\t" \
+        "ds_read_b32 %1, %1 offset:%11+9216\n\t" \
+        "ds_read_b32 %2, %2 offset:%11+10240\n\t" \
+        "ds_read_b32 %3, %3 offset:%11+11264\n\t" \
+        "ds_read_b32 %4, %4 offset:%11+12288\n\t" \
+        "ds_read_b32 %5, %5 offset:%11+13312\n\t" \
+        "ds_read_b32 %6, %6 offset:%11+14336\n\t" \
+        "ds_read_b32 %7, %7 offset:%11+15360"                                                                                 \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(two), "n"(OFFS)                                            \
+        : "memory")
+// N chunks against the LUT at LDS byte offset O as one straight-line half-block pipeline: 16 reads
+// in flight at the start, then always 8 in flight under the 8 dependent adds of the previous half
+// block; acc[c] = dis0 + the 16 table values of chunk c, left to right.  No control flow inside.
+template <int N, int O>
+__device__ __forceinline__ void adc16_pipeline(const uint4 (&c)[N], float dis0, uint32_t two, float (&acc)[N]) {
+    float hb[2 * N][8];
+#define VLQ_ISSUE(S)                                                                                    \
+    do {                                                                                                \
+        float (&v)[8] = hb[S];                                                                          \
+        if ((S) % 2 == 0) VLQ_G8LO_NWI(O, c[(S) / 2].x, c[(S) / 2].y);                                   \
+        else VLQ_G8HI_NWI(O, c[(S) / 2].z, c[(S) / 2].w);                                                \
+    } while (0)
+    VLQ_ISSUE(0);
+    VLQ_ISSUE(1);
+#pragma unroll
+    for (int s = 0; s < 2 * N; s++) {
+        if (s == 2 * N - 1) VLQ_WAIT8(0, hb[s]); else VLQ_WAIT8(8, hb[s]);
+        float d = (s % 2 == 0) ? dis0 : acc[s / 2];
+#pragma unroll
+        for (int m = 0; m < 8; m++) d = __fadd_rn(d, hb[s][m]);
+        asm volatile("" : "+v"(d));
+        acc[s / 2] = d;
+        if (s + 2 < 2 * N) VLQ_ISSUE(s + 2);
+    }
+#undef VLQ_ISSUE
+}
+
 template <int BUF>
 __device__ __forceinline__ float adc16_fixed(const uint4 cc, float dis, uint32_t two) {
     float v[16];
