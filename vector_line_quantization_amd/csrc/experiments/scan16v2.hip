@@ -157,12 +157,29 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 3) void scan16v2_kernel(ScanArg
             u64 okm[PD];
             u64 any = 0;
 #pragma unroll
+            for (int u = 0; u < PD; u++) d[u] = 3.402823466e+38f;
+            // the wave's chunks of this group as ONE straight-line half-block pipeline (scan16_common.cuh)
+            const uint32_t left = nit > i0 ? nit - i0 : 0u;              // wave-uniform
+            if (left >= 4) {
+                adc16_pipeline<4, B * 16384>(C, dis0, two, d);
+            } else if (left == 3) {
+                const uint4 c3[3] = {C[0], C[1], C[2]};
+                float a3[3];
+                adc16_pipeline<3, B * 16384>(c3, dis0, two, a3);
+                d[0] = a3[0]; d[1] = a3[1]; d[2] = a3[2];
+            } else if (left == 2) {
+                const uint4 c2[2] = {C[0], C[1]};
+                float a2[2];
+                adc16_pipeline<2, B * 16384>(c2, dis0, two, a2);
+                d[0] = a2[0]; d[1] = a2[1];
+            } else if (left == 1) {
+                d[0] = adc16_fixed<B>(C[0], dis0, two);
+            }
+#pragma unroll
             for (int u = 0; u < PD; u++) {
                 const uint32_t it = i0 + u;
                 const uint32_t off = lane_off + it * 4096u;
-                d[u] = 3.402823466e+38f;
-                if (it < nit) d[u] = adc16_fixed<B>(C[u], dis0, two);     // wave-uniform guard
-                okm[u] = __builtin_amdgcn_ballot_w64(off < scanb && d[u] < sel.thr);
+                okm[u] = __builtin_amdgcn_ballot_w64(it < nit && off < scanb && d[u] < sel.thr);
                 any |= okm[u];
                 // the register just consumed gets the chunk this wave needs in it next: PD chunks
                 // further down this list, or chunk u of the next list
