@@ -8,7 +8,7 @@ import vector_line_quantization_amd as vlq
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 64000000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-d, M, nprobe, k = 128, 16, 32, 10
+d, M, nprobe, k = int(os.environ.get("DIM", "128")), 16, int(os.environ.get("NPROBE", "32")), int(os.environ.get("K", "10"))
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 g = vlq.GpuIVFPQ(d, nlist, M, 8)
@@ -34,3 +34,11 @@ p = g.profile_read(); _n, ncode = g.stats()
 scan_ms = p["scan_ms"] / reps
 print("nb=%d nlist=%d (%.0f codes per list) nq=%d: scan kernel %.3f ms, %.0f codes per query, %.2f TB/s of code bytes = %.2f of 8 TB/s" % (
     nb, nlist, nb / nlist, nq, scan_ms, ncode / reps / nq, ncode / reps * 16 / (scan_ms * 1e-3) / 1e12, ncode / reps * 16 / (scan_ms * 1e-3) / 8e12))
+g.profile(1); g.profile_read(reset=True)
+t0 = time.time()
+for _ in range(reps): g.search(x, nprobe, k, D=D, I=I)
+torch.cuda.synchronize()
+wall = (time.time() - t0) / reps * 1e3
+p = g.profile_read()
+print("whole search %.3f ms per batch (%.2f M queries/s): coarse %.3f, tables+order %.3f, scan %.3f ms" % (
+    wall, nq / wall / 1e3, p["coarse_ms"] / reps, p["tables_ms"] / reps, p["scan_ms"] / reps))

@@ -244,6 +244,10 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.max_codes = h->max_codes;
         a.store_pairs = store_pairs;
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
+        a.long_lists = h->ntotal >= (int64_t)h->nlist * 1024;   // mean list >= 4 chunks of 256 codes
+#ifdef VLQ_EXPERIMENTS
+        if (getenv("VLQ_NOPIPE")) a.long_lists = 0;
+#endif
         if (fast16) {
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);   // query ordering is booked with the table stage

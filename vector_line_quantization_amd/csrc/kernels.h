@@ -59,6 +59,7 @@ struct ScanArgs {
     int imi_nbits = 0;           // > 0: table mode 2 -- key = i0 | i1 << imi_nbits, term2 rows per coarse SUB-index
     const int* qorder = nullptr; // optional processing order of the queries (scan16 only)
     int nsplit = 1;              // scan16: workgroups per query; > 1: D / I are [nsplit][nq][k] partial rows
+    int long_lists = 0;          // scan16: mean list length >= 4 chunks -- selects the pipelined pair loop for k > 64 too
     int xcd_chunk = 0;           // set by the launcher
 };
 void launch_scan(const ScanArgs& a, hipStream_t s);

@@ -22,8 +22,8 @@
 
 namespace vlq {
 
-template <int KPL, int NW, int NBUF>
-__global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_region) {
+template <int KPL, int NW, int NBUF, bool PIPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((KPL == 4 && PIPE) ? 4 : 1))) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
     constexpr int NI = 16 / NW;       // float4 of the LUT per thread
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
     int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64 * QR) +
                                                ProbeMeta::bytes(a.nprobe));    // cut, nlive
     uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
+    uint32_t* wg_thr = reinterpret_cast<uint32_t*>(ord + ((a.nprobe + 1) & ~1));  // min of the waves' k-th distances
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // adc16_fixed() addresses the LUT buffers at LDS offsets 0 / 16384
@@ -74,13 +75,14 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
-        if (lane == 0) { misc[0] = cut; misc[1] = nl; }
+        if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
     __syncthreads();
     const int nlive = misc[1];
 
-    WaveSelect<KPL, QR> sel;
+    WaveSelect<KPL, QR, KPL >= 4> sel;   // k > 64: the merge network stays out of the scan loop's register budget
     sel.init(a.k, queue + wave * 64 * QR, lane);
+    sel.attach(wg_thr);
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         uint4 cc = c0, cd = c1;
         prefetch(i + 1);
         __syncthreads();
+        sel.refresh();
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;
@@ -133,9 +136,10 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
             // two chunks per trip in four half blocks of 8 lookups: while the 8 dependent adds of one
             // half block run, the next half block's reads are in flight (counted lgkmcnt) -- LDS and
             // VALU overlap inside a wave instead of only between waves
-            // (only with one key per lane: the 32 extra registers cost the longer selections a wave of
-            // occupancy, measured k = 100: 1.27 -> 1.47 ms)
-            for (; KPL == 1 && j0 + NT < len; j0 += 2 * NT) {
+            // (PIPE: always with one key per lane; the 32 extra registers cost the longer selections a
+            // wave of occupancy -- measured k = 100 on 244-code lists: 1.27 -> 1.47 ms -- so k > 64
+            // takes it only for indexes with long lists)
+            for (; PIPE && j0 + NT < len; j0 += 2 * NT) {
                 const uint32_t ja = j0 + lane, jb = ja + NT;
                 const uint4 ca = cc, cb = cd;
                 cc = cp[min(jb + NT, len - 1)];              // the next trip's two chunks
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(64 * NW) void scan16_kernel(ScanArgs a, int lut_reg
         if (NBUF == 2) buf ^= 1;
     }
 
+    sel.attach(nullptr);
     merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                         [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
@@ -314,11 +319,11 @@ void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
     else launch_scan16_short_t<16>(a, (int)region, smem, s);
 }
 
-template <int KPL, int NW, int NBUF>
+template <int KPL, int NW, int NBUF, bool PIPE>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF>), smem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE>), smem);
     const unsigned grid = (unsigned)(8 * a.xcd_chunk);
-    hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
+    hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
 
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
@@ -336,12 +341,21 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 64;
+    const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
     const size_t smem = lutb + tail;
-    if (a.k <= 64) launch_scan16_t<1, 4, 2>(a, (int)lutb, smem, s);
-    else if (a.k <= 256) launch_scan16_t<4, 4, 2>(a, (int)lutb, smem, s);
-    else if (a.k <= 512) launch_scan16_t<8, 4, 2>(a, (int)lutb, smem, s);
-    else launch_scan16_t<16, 4, 2>(a, (int)lutb, smem, s);
+#ifdef VLQ_EXPERIMENTS
+    if (getenv("VLQ_FORCE_KPL4")) {     // the k > 64 kernel on a small k: separates code structure from insertion statistics
+        if (a.long_lists) launch_scan16_t<4, 4, 2, true>(a, (int)lutb, smem, s);
+        else launch_scan16_t<4, 4, 2, false>(a, (int)lutb, smem, s);
+        return;
+    }
+#endif
+    if (a.k <= 64) launch_scan16_t<1, 4, 2, true>(a, (int)lutb, smem, s);
+    else if (a.k <= 256) {
+        if (a.long_lists) launch_scan16_t<4, 4, 2, true>(a, (int)lutb, smem, s);
+        else launch_scan16_t<4, 4, 2, false>(a, (int)lutb, smem, s);
+    } else if (a.k <= 512) launch_scan16_t<8, 4, 2, false>(a, (int)lutb, smem, s);
+    else launch_scan16_t<16, 4, 2, false>(a, (int)lutb, smem, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -9,8 +9,8 @@
 namespace vlq {
 
 // resolve(p, lkey, loff): list id and list start offset of probe p
-template <int KPL, int NW = 4, int QR = 1, typename Resolve>
-__device__ __forceinline__ void merge_and_emit(WaveSelect<KPL, QR>& sel, unsigned char* smraw,
+template <int KPL, int NW = 4, int QR = 1, typename Sel, typename Resolve>
+__device__ __forceinline__ void merge_and_emit(Sel& sel, unsigned char* smraw,
                                                const uint32_t* cum, const ScanArgs& a, int64_t q,
                                                int wave, int lane, Resolve resolve) {
     sel.flush();

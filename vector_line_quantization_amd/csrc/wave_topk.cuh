@@ -38,12 +38,27 @@ __device__ __forceinline__ u64 make_key(float dis, uint32_t pos) {
     return ((u64)f32_to_ordered(dis) << 32) | pos;
 }
 
+// value of lane (lane ^ stride); stride is a compile-time constant after unrolling.  Strides 1, 2
+// and 8 are DPP moves (VALU, no LDS round trip), 4 and 16 the LDS crossbar without an address
+// register (ds_swizzle bit mode), 32 a ds_bpermute.
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int stride) {
+    switch (stride) {
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+        case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
+        case 4: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10));           // and 0x1f, xor 4
+        case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
+        default: return (uint32_t)__shfl_xor((int)v, stride, 64);
+    }
+}
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, mask, 64);
-    hi = __shfl_xor(hi, mask, 64);
+    lo = lane_xor_u32(lo, mask);
+    hi = lane_xor_u32(hi, mask);
     return ((u64)hi << 32) | lo;
 }
+// compare-exchange results with one 64-bit compare: the smaller (want_min) or larger of (a, b)
+__device__ __forceinline__ u64 pick64(u64 a, u64 b, bool want_min) { return ((a < b) == want_min) ? a : b; }
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl(lo, src, 64);
@@ -62,7 +77,7 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
             u64 other = shfl_xor_u64(key, stride);
             bool up = (lane & size) == 0;        // size == 64: always ascending
             bool lower = (lane & stride) == 0;
-            key = (lower == up) ? umin64(key, other) : umax64(key, other);
+            key = pick64(key, other, lower == up);
         }
     }
     return key;
@@ -77,9 +92,10 @@ __device__ __forceinline__ void wave_bitonic_merge(u64 (&best)[KPL], int lane) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
             if ((r & rs) == 0) {
-                u64 a = best[r], b = best[r | rs];
-                best[r] = umin64(a, b);
-                best[r | rs] = umax64(a, b);
+                const u64 a = best[r], b = best[r | rs];
+                const bool lt = a < b;
+                best[r] = lt ? a : b;
+                best[r | rs] = lt ? b : a;
             }
         }
     }
@@ -89,7 +105,7 @@ __device__ __forceinline__ void wave_bitonic_merge(u64 (&best)[KPL], int lane) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
             u64 other = shfl_xor_u64(best[r], stride);
-            best[r] = lower ? umin64(best[r], other) : umax64(best[r], other);
+            best[r] = pick64(best[r], other, lower);
         }
     }
 }
@@ -109,8 +125,9 @@ __device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
                     if ((r & rs) == 0) {
                         const bool up = (((r * 64) & size) == 0) || size == 64 * R;
                         const u64 a = p[r], b = p[r | rs];
-                        p[r] = up ? umin64(a, b) : umax64(a, b);
-                        p[r | rs] = up ? umax64(a, b) : umin64(a, b);
+                        const bool lt = (a < b) == up;      // up is a compile-time constant here
+                        p[r] = lt ? a : b;
+                        p[r | rs] = lt ? b : a;
                     }
                 }
             } else {
@@ -120,7 +137,7 @@ __device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
                     const int e = r * 64 + lane;
                     const bool up = ((e & size) == 0) || size == 64 * R;
                     const bool lower = (lane & stride) == 0;
-                    p[r] = (lower == up) ? umin64(p[r], other) : umax64(p[r], other);
+                    p[r] = pick64(p[r], other, lower == up);
                 }
             }
         }
@@ -132,53 +149,95 @@ __device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
 // QR = pending-queue capacity in units of 64 keys (LDS: 64*QR u64 per wave).  A flush costs one
 // sort of the pending keys plus one merge of the whole best list, so long lists (KPL >= 8) want
 // QR = 4: four times fewer merges of 512..1024 keys.
-template <int KPL, int QR = 1>
+// OUTLINE: the merge runs as a real function call (values in, values out -- all in registers), so
+// the register allocation of the caller's hot loop does not see the ~40 temporaries of the sort /
+// merge network; whatever has to be saved around the call is saved in the rare branch only.
+template <int KPL>
+struct BestList { u64 v[KPL]; float kth; };
+
+template <int KPL, int QR>
+__device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, const u64* queue, int npend, int k, int lane) {
+    u64 p[QR];
+#pragma unroll
+    for (int r = 0; r < QR; r++) p[r] = (r * 64 + lane < npend) ? queue[r * 64 + lane] : kMaxKey;
+    wave_sort_multi<QR>(p, lane);
+    // pending reversed (element e -> N-1-e) against the tail of the best list: bitonic split
+#pragma unroll
+    for (int r = 0; r < QR; r++) {
+        const u64 rev = shfl_u64(p[QR - 1 - r], 63 - lane);
+        b.v[KPL - QR + r] = umin64(b.v[KPL - QR + r], rev);
+    }
+    wave_bitonic_merge<KPL>(b.v, lane);
+    // distance part of element k-1 of the sorted best list
+    const int kr = (k - 1) >> 6, kl = (k - 1) & 63;
+    u64 row = b.v[0];
+#pragma unroll
+    for (int r = 1; r < KPL; r++) row = (r == kr) ? b.v[r] : row;
+    const u64 kth = shfl_u64(row, kl);
+    // a missing k-th (kMaxKey) keeps the threshold at FLT_MAX
+    b.kth = (kth == kMaxKey) ? 3.402823466e+38f : ordered_to_f32((uint32_t)(kth >> 32));
+    return b;
+}
+template <int KPL, int QR>
+__device__ __noinline__ BestList<KPL> flush_call(BestList<KPL> b, const u64* queue, int npend, int k, int lane) {
+    return flush_body<KPL, QR>(b, queue, npend, k, lane);
+}
+
+template <int KPL, int QR = 1, bool OUTLINE = false>
 struct WaveSelect {
     static_assert(QR <= KPL, "the pending queue cannot exceed the best list");
     u64 best[KPL];
-    float thr;        // admission threshold (distance of the k-th best, or FLT_MAX)
+    float thr;        // admission threshold: min(thr_own, bound shared by the workgroup)
+    float thr_own;    // distance of this wave's k-th best, or FLT_MAX
     int npend;        // entries parked in `queue` (wave-uniform)
     int k;
     int lane;
     u64* queue;
+    // Optional LDS word shared by the waves of a workgroup that select from disjoint parts of ONE
+    // stream (their lists are merged afterwards): the minimum of their k-th distances, as its
+    // ordered image.  A wave whose k-th best is T holds k keys with distance <= T, so a candidate of
+    // ANOTHER wave can still reach the merged top-k only if dis <= T.  `dis <= T` is `dis <
+    // nextup(T)`, so the hot loop keeps its one strict compare.  The own threshold stays strict
+    // (min(thr_own, nextup(T)) == thr_own when T == thr_own).
+    uint32_t* wg;
 
     __device__ __forceinline__ void init(int k_, u64* queue_, int lane_) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) best[r] = kMaxKey;
-        thr = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
+        thr = thr_own = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
+        wg = nullptr;
         npend = 0;
         k = k_;
         lane = lane_;
         queue = queue_;
     }
 
-    // distance part of element k-1 of the sorted best list
-    __device__ __forceinline__ void update_threshold() {
-        const int kr = (k - 1) >> 6, kl = (k - 1) & 63;
-        u64 row = best[0];
-#pragma unroll
-        for (int r = 1; r < KPL; r++) row = (r == kr) ? best[r] : row;
-        u64 kth = shfl_u64(row, kl);
-        // a missing k-th (kMaxKey) keeps the threshold at FLT_MAX
-        thr = (kth == kMaxKey) ? 3.402823466e+38f : ordered_to_f32((uint32_t)(kth >> 32));
-    }
-
     // merge the parked candidates into the best list
     __device__ __forceinline__ void flush() {
         if (npend == 0) return;
-        u64 p[QR];
+        BestList<KPL> b;
 #pragma unroll
-        for (int r = 0; r < QR; r++) p[r] = (r * 64 + lane < npend) ? queue[r * 64 + lane] : kMaxKey;
-        wave_sort_multi<QR>(p, lane);
-        // pending reversed (element e -> N-1-e) against the tail of the best list: bitonic split
+        for (int r = 0; r < KPL; r++) b.v[r] = best[r];
+        b = OUTLINE ? flush_call<KPL, QR>(b, queue, npend, k, lane) : flush_body<KPL, QR>(b, queue, npend, k, lane);
 #pragma unroll
-        for (int r = 0; r < QR; r++) {
-            const u64 rev = shfl_u64(p[QR - 1 - r], 63 - lane);
-            best[KPL - QR + r] = umin64(best[KPL - QR + r], rev);
-        }
-        wave_bitonic_merge<KPL>(best, lane);
+        for (int r = 0; r < KPL; r++) best[r] = b.v[r];
         npend = 0;
-        update_threshold();
+        // (wave-uniform: keep it in a scalar register)
+        thr = thr_own = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b.kth)));
+        if (wg) {
+            if (lane == 0) atomicMin(wg, f32_to_ordered(thr_own));
+            refresh();
+        }
+    }
+
+    // share thresholds with the other waves of the workgroup through *w (initialised by the caller
+    // to f32_to_ordered(FLT_MAX) before any wave flushes)
+    __device__ __forceinline__ void attach(uint32_t* w) { wg = w; }
+    // pick up the other waves' progress (cheap: one LDS broadcast read)
+    __device__ __forceinline__ void refresh() {
+        const float t = ordered_to_f32(*(volatile uint32_t*)wg) + 0.0f;      // -0 -> +0: nextup(-0) must be > +0
+        thr = __uint_as_float(__builtin_amdgcn_readfirstlane(
+            __float_as_uint(fminf(thr_own, ordered_to_f32(f32_to_ordered(t) + 1u)))));
     }
 
     // one candidate per lane (`valid` lanes only); wave-uniform control flow.
