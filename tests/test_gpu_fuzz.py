@@ -70,3 +70,29 @@ def test_random_configuration(seed):
     Do2, Io2 = ox.search_preassigned(xq, keys, cd, c["k"], store_pairs=bool(seed & 1), canonical=True)
     assert np.array_equal(bits(D2), bits(Do2)), c
     assert np.array_equal(I2, Io2), c
+
+
+@pytest.mark.parametrize("k,dup", [(10, 1), (64, 1), (100, 1), (100, 4), (128, 1), (200, 1), (256, 4), (400, 1), (1000, 1)])
+def test_long_lists_every_k_class(k, dup):
+    """Mean list length >= 1024: the pipelined two-chunk loop of scan16 for k <= 64 and, with the
+    `long_lists` switch, for the 128- and 256-key selections; larger k keeps the plain loop.  `dup`
+    stores every vector several times (exact distance ties across chunks and waves)."""
+    rng = np.random.default_rng(77 + k + dup)
+    d, nlist, M, nb, nq, nprobe = 32, 6, 16, 12000, 40, 4
+    centres = rng.random((3, d)).astype(np.float32)
+    gen = lambda n: (centres[rng.integers(0, 3, n)] + 0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    coarse = gen(nlist)
+    pq = (0.2 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    xb = np.repeat(gen(nb // dup), dup, axis=0)[rng.permutation(nb // dup * dup)]
+    xq = gen(nq)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    ox = pyoracle.OracleIndex(d, nlist, M, 8, coarse, pq)
+    g.add(xb)
+    ox.add(xb, None, canonical=True)
+    assert g.ntotal >= 1024 * nlist and max(g.list_length(i) for i in range(nlist)) > 2048
+    D, I = g.search(xq, nprobe, k)
+    Do, Io = ox.search(xq, nprobe, k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)

@@ -249,7 +249,7 @@ def test_add_in_batches_appends_on_device(name):
         assert np.array_equal(ids, ids1) and np.array_equal(c, c1)
 
 
-@pytest.mark.parametrize("k", [1, 64, 65, 256, 257, 512, 513, 1024])
+@pytest.mark.parametrize("k", [1, 64, 65, 100, 128, 129, 256, 257, 512, 513, 1024])
 def test_large_k_and_k_boundaries(k):
     """k at the edges of the per-lane key counts of the wave select (1/4/16)."""
     case = Case("deep_like_dsub6")

@@ -247,6 +247,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.long_lists = h->ntotal >= (int64_t)h->nlist * 1024;   // mean list >= 4 chunks of 256 codes
 #ifdef VLQ_EXPERIMENTS
         if (getenv("VLQ_NOPIPE")) a.long_lists = 0;
+        if (getenv("VLQ_PIPE")) a.long_lists = 1;
 #endif
         if (fast16) {
             if (ni >= 1024 && h->nlist <= (1 << 22)) {

@@ -23,7 +23,7 @@
 namespace vlq {
 
 template <int KPL, int NW, int NBUF, bool PIPE>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((KPL == 4 && PIPE) ? 4 : 1))) void scan16_kernel(ScanArgs a, int lut_region) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL == 4 || KPL == 2) && PIPE) ? 4 : 1))) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
     constexpr int NI = 16 / NW;       // float4 of the LUT per thread
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((KPL ==
     __syncthreads();
     const int nlive = misc[1];
 
-    WaveSelect<KPL, QR, KPL >= 4> sel;   // k > 64: the merge network stays out of the scan loop's register budget
+    WaveSelect<KPL, QR, KPL >= 2> sel;   // k > 64: the merge network stays out of the scan loop's register budget
     sel.init(a.k, queue + wave * 64 * QR, lane);
     sel.attach(wg_thr);
 
@@ -351,7 +351,10 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     }
 #endif
     if (a.k <= 64) launch_scan16_t<1, 4, 2, true>(a, (int)lutb, smem, s);
-    else if (a.k <= 256) {
+    else if (a.k <= 128) {          // recall@100: half the merge network of the 256-key list
+        if (a.long_lists) launch_scan16_t<2, 4, 2, true>(a, (int)lutb, smem, s);
+        else launch_scan16_t<2, 4, 2, false>(a, (int)lutb, smem, s);
+    } else if (a.k <= 256) {
         if (a.long_lists) launch_scan16_t<4, 4, 2, true>(a, (int)lutb, smem, s);
         else launch_scan16_t<4, 4, 2, false>(a, (int)lutb, smem, s);
     } else if (a.k <= 512) launch_scan16_t<8, 4, 2, false>(a, (int)lutb, smem, s);
