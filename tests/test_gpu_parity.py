@@ -130,6 +130,37 @@ def test_coarse_select_row_sizes(nlist, nprobe):
     assert np.array_equal(keys, keyso)
 
 
+@pytest.mark.parametrize("nlist,d,nprobe", [(16384, 16, 64), (16384, 32, 10), (16448, 8, 1), (32768, 8, 100),
+                                            (65536, 4, 256), (131072, 4, 300), (131072, 8, 512)])
+def test_wide_rows_two_level_select(nlist, d, nprobe):
+    """nlist > 8192, a multiple of 64, at least 4 * nprobe column tiles: the distance kernel also writes
+    per-tile minima and the select reads only the tiles that can hold one of the nprobe nearest
+    centroids.  Same (distance, column) order as the oracle, with runs of exact ties inside and across
+    tiles, and the same leading entries as a selection that is too wide for the two-level path."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(nlist + nprobe)
+    M = 4
+    cent = rng.random((nlist, d)).astype(np.float32)
+    cent[nlist // 2:nlist // 2 + 100] = cent[3]             # ties inside a tile and across neighbours
+    cent[rng.integers(0, nlist, 500)] = cent[7]              # ties scattered over many tiles
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    xq = rng.random((70, d)).astype(np.float32)
+    xq[:8] = cent[3] + 0.001 * rng.standard_normal((8, d)).astype(np.float32)
+    xq[8:16] = cent[7]
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, M, 8, cent, pq)
+    cd, keys = g.coarse_search(xq, nprobe)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+    wide = min(1024, nlist // 256 + 1 + nprobe)              # fewer than 4 * nprobe tiles: one-level select
+    if wide > nprobe:
+        cd2, keys2 = g.coarse_search(xq, wide)
+        assert np.array_equal(bits(cd2[:, :nprobe]), bits(cd)) and np.array_equal(keys2[:, :nprobe], keys)
+
+
 @pytest.mark.parametrize("nq", [1, 3, 16, 100, 500])
 def test_small_batches_split_scan(nq):
     """Serving-size batches: a query's probes are split over up to 8 workgroups and the partial rows

@@ -111,18 +111,23 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
                 int64_t* keys_dev, bool zero_qnorm, bool direct) {
     TRY(h->ws_qn.reserve((size_t)n * sizeof(float)));
     TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
+    float* tmin = nullptr;
     if (direct) {
         vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
                                             h->nlist, h->d, h->stream);
     } else {
         if (zero_qnorm) HIP_TRY(hipMemsetAsync(h->ws_qn.p, 0, (size_t)n * sizeof(float), h->stream));
         else vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
+        if (vlq::coarse_tile_minima_ok(h->nlist, h->d, nprobe)) {
+            TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * sizeof(float)));
+            tmin = h->ws_tmin.as<float>();
+        }
         vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(),
                                      h->cnorm.as<float>(), h->ws_dist.as<float>(), n, h->nlist,
-                                     h->d, h->stream);
+                                     h->d, h->stream, tmin);
     }
     vlq::launch_coarse_select(h->ws_dist.as<float>(), n, h->nlist, nprobe, cdis_dev, keys_dev,
-                              h->stream);
+                              h->stream, tmin);
     HIP_TRY(hipGetLastError());
     return VLQ_OK;
 }
@@ -151,6 +156,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     float* sub = (float*)p;
     for (int m = 0; m < 2; m++) {
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
+        float* tmin = nullptr;
         if (dc < 16) {
             // compute_distance_table (ProductQuantizer.cpp:410-422): fvec_L2sqr per entry
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
@@ -160,10 +166,14 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
             TRY(h->ws_qn.reserve((size_t)n * 4));
             vlq::launch_row_norms(sub, n, dc, h->ws_qn.as<float>(), h->stream);
+            if (vlq::coarse_tile_minima_ok(kc, dc, T)) {
+                TRY(h->ws_tmin.reserve((size_t)n * (kc / 64) * sizeof(float)));
+                tmin = h->ws_tmin.as<float>();
+            }
             vlq::launch_coarse_distances(sub, cent, h->ws_qn.as<float>(), h->imi_norm.as<float>() + (size_t)m * kc,
-                                         tab[m], n, kc, dc, h->stream);
+                                         tab[m], n, kc, dc, h->stream, tmin);
         }
-        vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream);
+        vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
     }
     vlq::launch_imi_minsum(sv[0], si[0], sv[1], si[1], T, n, k, kc, h->imi_nbits, hv, hi, cdis_dev, keys_dev,
                            h->stream);
@@ -386,7 +396,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->list_off, &h->list_len, &h->list_rank, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->stats, &h->imi_cent,
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi};
     for (auto b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

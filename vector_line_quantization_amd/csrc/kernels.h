@@ -16,16 +16,20 @@ void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t 
 
 // out[i][j] = (qn[i] + cn[j]) - 2 * <q_i, c_j>   (utils.cpp:884), inner product =
 // k-ordered f32 MFMA chain.  out is [nq][nlist].
+// tmin != nullptr (only if coarse_tile_minima_ok): also tmin[i][t] = min of out[i][64t .. 64t+63]
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
-                             float* out, int64_t nq, int nlist, int d, hipStream_t s);
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin = nullptr);
+// wide rows and few probes: the distance kernel can hand the select a [nq][nlist/64] matrix of tile minima
+bool coarse_tile_minima_ok(int nlist, int d, int nprobe);
 
 // < 20 queries: direct fvec_L2sqr per pair (utils.cpp:757-786)
 void launch_coarse_distances_direct(const float* q, const float* c, float* out, int64_t nq,
                                     int nlist, int d, hipStream_t s);
 
 // per row: the nprobe smallest (distance, column), ascending; pads -1 / FLT_MAX
+// tmin != nullptr: two-level select that reads only the tiles whose minimum can matter
 void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, float* cdis,
-                          int64_t* keys, hipStream_t s);
+                          int64_t* keys, hipStream_t s, const float* tmin = nullptr);
 
 // PQ tables.  mode 0: <x_m, cent_mj>  (ProductQuantizer.cpp:424-436)
 //             mode 1: |x_m - cent_mj|^2 (ProductQuantizer.cpp:410-422)

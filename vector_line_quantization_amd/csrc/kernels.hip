@@ -168,17 +168,21 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(
 // j is multiplied and written to the other buffer afterwards; one barrier per tile.
 // Same k order (0,1,2,...) and epilogue as coarse_dist_kernel -> identical bits.
 // ---------------------------------------------------------------------------
-template <int NU, bool VEC>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
+// TMIN (nlist % 64 == 0): also writes tmin[row][tile] = the minimum of the row's 64 distances in
+// that column tile -- 1/64 of the matrix -- from which coarse_select_tiled_kernel finds the few
+// tiles that can hold one of the nprobe nearest centroids and reads only those.
+template <int NU, bool VEC, bool TMIN>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
 __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
     const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d,
-    int tiles_per_block) {
+    int tiles_per_block, float* __restrict__ tmin) {
     constexpr int KS = 4 * NU;        // k-pair steps
     constexpr int S = KS + 4;         // padded row stride (floats) of a parity plane
     extern __shared__ __attribute__((aligned(16))) float sm[];   // 2 buffers x [2 parity][64][S]
     constexpr int BUF = 2 * 64 * S;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int h = lane >> 5, r = lane & 31;
+    float* tms = sm + 2 * BUF + wave * (32 * 17);     // TMIN: this wave's [32 rows][16 tiles + 1] staging
     const int64_t i0 = (int64_t)blockIdx.x * 128;
     const int tile0 = blockIdx.y * tiles_per_block;
     const int ntiles = (nlist + 63) / 64;
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         // 16-byte stores that cover whole 128-byte lines (8 rows per instruction) --
         // 4x fewer store instructions than dword stores, which were issue-bound.
         const bool full = (tile * 64 + 64 <= nlist) && ((nlist & 3) == 0);
+        float mrow[4];
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
             const int col = tile * 64 + tj * 32 + r;
@@ -327,6 +332,10 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                     if (row < nq)
                         *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) =
                             make_float4(v[0], v[1], v[2], v[3]);
+                    if (TMIN) {
+                        const float m4 = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                        mrow[g] = tj == 0 ? m4 : fminf(mrow[g], m4);
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -336,16 +345,42 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                 }
             }
         }
+        if (TMIN) {
+            // lane (r = 4q + i, h) holds row 8g + 4h + i, columns 4q..4q+3 of both halves: the row's
+            // tile minimum is the minimum over q, i.e. over lane bits 2..4
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float m = mrow[g];
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 4)));
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 8)));
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 16)));
+                if (r < 4) tms[(8 * g + 4 * h + r) * 17 + ((tile - tile0) & 15)] = m;
+            }
+            // a wave owns its 32 rows: every 16 tiles (and at the end) it writes 16 consecutive
+            // minima per row, 64 contiguous bytes, instead of 4-byte stores one matrix row apart
+            const int done = tile - tile0 + 1;
+            if ((done & 15) == 0 || tile + 1 == tend) {
+                __builtin_amdgcn_wave_barrier();
+                const int ncol = ((done - 1) & 15) + 1, t0 = tile + 1 - ncol, c = lane & 15;
+#pragma unroll
+                for (int rr = 0; rr < 32; rr += 4) {
+                    const int lr = rr + (lane >> 4);
+                    const int64_t row = i0 + wave * 32 + lr;
+                    if (c < ncol && row < nq) tmin[row * (nlist >> 6) + t0 + c] = tms[lr * 17 + c];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         __syncthreads();
     }
 }
 
-template <int NU, bool VEC>
+template <int NU, bool VEC, bool TMIN>
 static void launch_coarse_areg_t(const float* q, const float* c, const float* qn, const float* cn,
-                               float* out, int64_t nq, int nlist, int d, hipStream_t s) {
+                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
     constexpr int S = 4 * NU + 4;
-    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC>), smem);
+    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN ? (size_t)4 * 32 * 17 * sizeof(float) : 0);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC, TMIN>), smem);
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
     // tiles per workgroup: the MFMA pipe of a CU is shared by its (up to 2) resident
@@ -359,25 +394,32 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
         if (cost < best_cost) { best_cost = cost; best_t = tpb; }
     }
     dim3 grid((unsigned)rb, (unsigned)((ntiles + best_t - 1) / best_t));
-    hipLaunchKernelGGL((coarse_dist_areg_kernel<NU, VEC>), grid, dim3(256), smem, s, q, c, qn, cn, out,
-                       nq, nlist, d, best_t);
+    hipLaunchKernelGGL((coarse_dist_areg_kernel<NU, VEC, TMIN>), grid, dim3(256), smem, s, q, c, qn, cn, out,
+                       nq, nlist, d, best_t, tmin);
 }
 
 template <int NU>
 static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
-                               float* out, int64_t nq, int nlist, int d, hipStream_t s) {
-    if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true>(q, c, qn, cn, out, nq, nlist, d, s);
-    else launch_coarse_areg_t<NU, false>(q, c, qn, cn, out, nq, nlist, d, s);
+                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
+    if (tmin) launch_coarse_areg_t<NU, true, true>(q, c, qn, cn, out, nq, nlist, d, tmin, s);   // coarse_tile_minima_ok
+    else if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true, false>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
+    else launch_coarse_areg_t<NU, false, false>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
+}
+
+// tile minima are produced by the d <= 128 kernels for whole 64-column tiles and 16-byte row loads
+bool coarse_tile_minima_ok(int nlist, int d, int nprobe) {
+    return d <= 128 && d >= 4 && d % 4 == 0 && nlist % 64 == 0 && nlist > 8192 && nlist <= 2048 * 64 &&
+           nlist / 64 >= 4 * nprobe;
 }
 
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
-                             float* out, int64_t nq, int nlist, int d, hipStream_t s) {
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin) {
     if (nq <= 0 || nlist <= 0) return;
     if (d <= 128) {
-        if (d <= 32) launch_coarse_areg<4>(q, c, qn, cn, out, nq, nlist, d, s);
-        else if (d <= 64) launch_coarse_areg<8>(q, c, qn, cn, out, nq, nlist, d, s);
-        else if (d <= 96) launch_coarse_areg<12>(q, c, qn, cn, out, nq, nlist, d, s);
-        else launch_coarse_areg<16>(q, c, qn, cn, out, nq, nlist, d, s);
+        if (d <= 32) launch_coarse_areg<4>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
+        else if (d <= 64) launch_coarse_areg<8>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
+        else if (d <= 96) launch_coarse_areg<12>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
+        else launch_coarse_areg<16>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
         return;
     }
     constexpr int KC = 64;
@@ -555,10 +597,82 @@ __global__ __launch_bounds__(256) void coarse_select_reg_kernel(const float* __r
     }
 }
 
+// Two-level select for wide rows (nlist > 8192): with the tile minima of the distance kernel, the
+// nprobe-th smallest tile minimum T bounds the nprobe-th smallest distance from above (nprobe tiles
+// hold an element <= T each), and a tile whose minimum is above T holds no element <= T.  So only
+// the tiles with minimum <= T -- nprobe of them unless minima tie -- are read: 256 B per tile
+// instead of the whole row, and the exact (distance, column) selection runs over those.
+template <int KPL>
+__global__ __launch_bounds__(256) void coarse_select_tiled_kernel(const float* __restrict__ dist,
+                                                                  const float* __restrict__ tmin, int64_t nq,
+                                                                  int nlist, int nprobe, float* __restrict__ cdis,
+                                                                  int64_t* __restrict__ keys) {
+    __shared__ u64 queue[4][64];
+    __shared__ uint16_t qual[4][2048];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;   // whole wave; no workgroup barrier below
+    const int ntiles = nlist >> 6;
+    const float* tm = tmin + q * ntiles;
+    WaveSelect<KPL> sel;
+    sel.init(nprobe, queue[wave], lane);
+    for (int j0 = 0; j0 < ntiles; j0 += 64) {
+        const int j = j0 + lane;
+        sel.offer(tm[min(j, ntiles - 1)], (uint32_t)j, j < ntiles);
+    }
+    sel.flush();
+    const float T = sel.thr_own;           // FLT_MAX when fewer than nprobe tiles hold anything admissible
+    int nqual = 0;
+    for (int j0 = 0; j0 < ntiles; j0 += 64) {
+        const int j = j0 + lane;
+        const float v = tm[min(j, ntiles - 1)];
+        const bool ok = j < ntiles && v <= T && v < FLT_MAX_F;
+        const u64 mask = __ballot(ok);
+        if (ok) qual[wave][nqual + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+        nqual += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    sel.init(nprobe, queue[wave], lane);
+    const float* row = dist + q * nlist;
+    constexpr int PF = 8;                  // tiles in flight per wave
+    for (int b = 0; b < nqual; b += PF) {
+        float v[PF];
+        int tile[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            tile[u] = qual[wave][min(b + u, nqual - 1)];
+            v[u] = row[tile[u] * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (b + u < nqual) sel.offer(v[u], (uint32_t)(tile[u] * 64 + lane), true);   // ascending positions
+    }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < nprobe) {
+            const u64 key = sel.best[r];
+            const bool miss = key == kMaxKey;
+            cdis[q * nprobe + e] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+            keys[q * nprobe + e] = miss ? -1 : (int64_t)(uint32_t)key;
+        }
+    }
+}
+
 void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, float* cdis,
-                          int64_t* keys, hipStream_t s) {
+                          int64_t* keys, hipStream_t s, const float* tmin) {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (tmin) {
+        if (nprobe <= 64)
+            hipLaunchKernelGGL(coarse_select_tiled_kernel<1>, grid, block, 0, s, dist, tmin, nq, nlist, nprobe, cdis, keys);
+        else if (nprobe <= 256)
+            hipLaunchKernelGGL(coarse_select_tiled_kernel<4>, grid, block, 0, s, dist, tmin, nq, nlist, nprobe, cdis, keys);
+        else
+            hipLaunchKernelGGL(coarse_select_tiled_kernel<16>, grid, block, 0, s, dist, tmin, nq, nlist, nprobe, cdis, keys);
+        return;
+    }
     if (nprobe <= 64 && (nlist & 3) == 0 && nlist >= 256 && nlist <= 8192) {
         if (nlist <= 1024)
             hipLaunchKernelGGL(coarse_select_reg_kernel<4>, grid, block, 0, s, dist, nq, nlist, nprobe, cdis, keys);
