@@ -7,7 +7,7 @@ import numpy as np, torch
 import vector_line_quantization_amd as vlq
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 50000000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-d, M, nq, nprobe, k = 128, 16, 10000, 32, 10
+d, M, nq, nprobe, k = int(os.environ.get('DIM', 128)), 16, 10000, int(os.environ.get('NPROBE', 32)), int(os.environ.get('K', 10))
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev); gen.manual_seed(5)
 centres = torch.rand((nlist, d), generator=gen, device=dev)
@@ -21,10 +21,10 @@ def batch(i, n):
     pick = torch.randint(0, nlist, (n,), generator=gb, device=dev)
     return (centres[pick] + 0.02 * torch.randn((n, d), generator=gb, device=dev)).contiguous()
 t0 = time.time()
-step = 1000000
+step = int(os.environ.get('BATCH', 1000000))
 for i in range(0, nb, step):
     g.add(batch(i // step, min(step, nb - i)))
-    if (i // step) % 10 == 9:
+    if (i // step) % 10 == 9 or i + step >= nb:
         torch.cuda.synchronize(); print("  added %d M in %.1f s" % ((i + step) // 1000000, time.time() - t0), flush=True)
 torch.cuda.synchronize()
 dt = time.time() - t0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Inverted-multi-index configuration timing (kernel experiments): IMI 2 x NBITS, table type 2.
-   python tools/time_imi.py [nq]   env: NBITS (default 10), NB, NPROBE, K"""
+   python tools/time_imi.py [nq]   env: NBITS (default 10), NB, BATCH, NPROBE, K"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,11 +16,14 @@ g.set_imi_centroids(nbits, imi)
 g.set_pq_centroids((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2)
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
 t0 = time.time()
-for i in range(0, nb, 1000000):
-    n = min(1000000, nb - i)
+step = E("BATCH", 1000000)
+for i in range(0, nb, step):
+    n = min(step, nb - i)
     g.add(torch.rand((n, d), device="cuda", generator=gen))
+    if (i // step) % 10 == 9:
+        torch.cuda.synchronize(); print("  added %d M in %.1f s" % ((i + n) // 1000000, time.time() - t0), flush=True)
 torch.cuda.synchronize()
-print("added %d vectors into %d lists in %.1f s" % (nb, nlist, time.time() - t0), flush=True)
+print("added %d vectors into %d lists in %.1f s, device memory in use %.1f GB" % (nb, nlist, time.time() - t0, (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9), flush=True)
 xq = torch.rand((nq, d), device="cuda", generator=gen)
 D = torch.empty((nq, k), dtype=torch.float32, device="cuda"); I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
 for _ in range(2): g.search(xq, nprobe, k, D=D, I=I)

@@ -338,6 +338,14 @@ int read_bad_key(vlq_ivfpq_t h) {
 
 }  // namespace
 
+static vlq::ListStore list_store(vlq_ivfpq_t h) {
+    vlq::ListStore ls;
+    ls.nlist = h->nlist; ls.code_size = h->M;
+    ls.codes = &h->codes; ls.ids = &h->ids; ls.off = &h->list_off; ls.len = &h->list_len;
+    ls.h_off = &h->h_list_off; ls.h_len = &h->h_list_len; ls.h_stale = &h->h_lists_stale;
+    return ls;
+}
+
 extern "C" {
 
 int vlq_version(void) { return 100; }
@@ -589,6 +597,7 @@ int vlq_ivfpq_set_lists(vlq_ivfpq_t h, const uint8_t* codes, const int64_t* ids,
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->h_list_off = off;
     h->h_list_len.swap(len);
+    h->h_lists_stale = false;
     h->ntotal = ntotal;
     h->have_lists = true;
     return VLQ_OK;
@@ -599,6 +608,11 @@ int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h) { return h ? h->ntotal : -1; }
 int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len) {
     if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
     if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
+    if (h->h_lists_stale) {
+        TRY(set_dev(h));
+        vlq::ListStore ls = list_store(h);
+        TRY(vlq::lists_sync_host(ls, h->stream));
+    }
     *len = h->h_list_len[list_id];
     return VLQ_OK;
 }
@@ -607,6 +621,10 @@ int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* 
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     if (list_id < 0 || list_id >= h->nlist) return fail(VLQ_ERR_INVALID, "list id out of range");
     TRY(set_dev(h));
+    {
+        vlq::ListStore ls = list_store(h);
+        TRY(vlq::lists_sync_host(ls, h->stream));
+    }
     const int64_t o = h->h_list_off[list_id], len = h->h_list_len[list_id];
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (len > 0 && codes_out)
@@ -788,7 +806,7 @@ int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids)
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
     // encode and append on the device (IndexIVFPQ.cpp:192-272; gpu/impl/IVFPQ.cu:197-426,
-    // gpu/impl/InvertedListAppend.cu:122-247): nothing but the per-list counts visits the host
+    // gpu/impl/InvertedListAppend.cu:122-247): nothing but an overflow flag and two totals visits the host
     const void* xd;
     TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     TRY(h->ws_assign.reserve((size_t)n * 8));
@@ -796,23 +814,14 @@ int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids)
     TRY(encode_dev(h, n, (const float*)xd, h->ws_assign.as<int64_t>(), h->ws_codes.as<uint8_t>()));
     const void* idd = nullptr;
     if (xids) TRY(stage_in(h, xids, (size_t)n * 8, h->ws_keys_in, &idd));
-    vlq::ListStore ls;
-    ls.nlist = h->nlist; ls.code_size = h->M;
-    ls.codes = &h->codes; ls.ids = &h->ids; ls.off = &h->list_off; ls.len = &h->list_len;
-    ls.h_off = &h->h_list_off; ls.h_len = &h->h_list_len;
+    vlq::ListStore ls = list_store(h);
     TRY(vlq::lists_append(ls, h->ws_append, n, h->ws_assign.as<int64_t>(), nullptr, h->ws_codes.as<uint8_t>(),
                           nullptr, (const int64_t*)idd, h->ntotal, h->stream));
     h->ntotal += n;                                             // IndexIVFPQ.cpp:271
     return VLQ_OK;
 }
 
-static vlq::ListStore list_store(vlq_ivfpq_t h) {
-    vlq::ListStore ls;
-    ls.nlist = h->nlist; ls.code_size = h->M;
-    ls.codes = &h->codes; ls.ids = &h->ids; ls.off = &h->list_off; ls.len = &h->list_len;
-    ls.h_off = &h->h_list_off; ls.h_len = &h->h_list_len;
-    return ls;
-}
+
 
 int vlq_ivfpq_reserve_memory(vlq_ivfpq_t h, int64_t num_vecs) {
     if (!h || num_vecs < 0) return fail(VLQ_ERR_INVALID, "bad argument");

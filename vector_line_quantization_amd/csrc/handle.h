@@ -94,7 +94,8 @@ struct vlq_ivfpq_s {
     int imi_nbits = 0;
     DevBuf imi_cent, imi_norm, imi_virtual, ws_imi;
     bool have_coarse = false, have_pq = false, term2_valid = false, have_lists = false;
-    std::vector<int64_t> h_list_off, h_list_len;
+    std::vector<int64_t> h_list_off, h_list_len;   // host copies, refreshed on demand (lists_sync_host)
+    bool h_lists_stale = false;
     AppendWs ws_append;
 
     // workspace

@@ -13,6 +13,7 @@ struct vlq_line_s {
     DevBuf edge_info, edge_dist, lambda_info, codes, lambdas, ids, line_off, line_len;   // lists.h layout
     bool have_graph = false, have_lambda = false;
     std::vector<int64_t> h_line_off, h_line_len;
+    bool h_lines_stale = false;
     AppendWs ws_append;
     std::vector<float> h_lambda;
     DevBuf ws_near, ws_line, ws_lamf, ws_lamb, ws_res, ws_codes, ws_sel_line, ws_sel_b2, ws_sel_g, ws_sel_meta, ws_sel_cnt,
@@ -72,6 +73,14 @@ int encode_dev(vlq_line_t h, int64_t n, const float* xd) {
 }
 
 }  // namespace
+
+static vlq::ListStore line_store(vlq_line_t h) {
+    vlq::ListStore ls;
+    ls.nlist = h->nlines; ls.code_size = h->base->M;
+    ls.codes = &h->codes; ls.lambdas = &h->lambdas; ls.ids = &h->ids; ls.off = &h->line_off; ls.len = &h->line_len;
+    ls.h_off = &h->h_line_off; ls.h_len = &h->h_line_len; ls.h_stale = &h->h_lines_stale;
+    return ls;
+}
 
 extern "C" {
 
@@ -277,6 +286,7 @@ int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambda
     HIP_TRY(hipStreamSynchronize(b->stream));
     h->h_line_off.swap(off);
     h->h_line_len.swap(len);
+    h->h_lines_stale = false;
     h->ntotal = nt;
     h->ntotal_added = nt;        // sequential ids continue from the loaded count (IndexIVFPQ.cpp:244)
     return VLQ_OK;
@@ -295,15 +305,11 @@ int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids) {
     TRY(encode_dev(h, n, (const float*)xd));
     const void* idd = nullptr;
     if (xids) TRY(stage_in(b, xids, (size_t)n * 8, h->ws_keys, &idd));
-    vlq::ListStore ls;
-    ls.nlist = h->nlines; ls.code_size = b->M;
-    ls.codes = &h->codes; ls.lambdas = &h->lambdas; ls.ids = &h->ids; ls.off = &h->line_off; ls.len = &h->line_len;
-    ls.h_off = &h->h_line_off; ls.h_len = &h->h_line_len;
+    vlq::ListStore ls = line_store(h);
+    int64_t placed = 0;
     TRY(vlq::lists_append(ls, h->ws_append, n, nullptr, h->ws_line.as<int32_t>(), h->ws_codes.as<uint8_t>(),
-                          h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream));
-    int64_t stored = 0;
-    for (int64_t v : h->h_line_len) stored += v;
-    h->ntotal = stored;
+                          h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream, &placed));
+    h->ntotal += placed;         // vectors without a line are dropped
     h->ntotal_added += n;
     return VLQ_OK;
 }
@@ -313,6 +319,11 @@ int64_t vlq_line_ntotal(vlq_line_t h) { return h ? h->ntotal : -1; }
 int vlq_line_list_length(vlq_line_t h, int64_t line, int64_t* len) {
     if (!h || !len) return fail(VLQ_ERR_INVALID, "null argument");
     if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
+    if (h->h_lines_stale) {
+        TRY(set_dev(h->base));
+        vlq::ListStore ls = line_store(h);
+        TRY(vlq::lists_sync_host(ls, h->base->stream));
+    }
     *len = h->h_line_len[line];
     return VLQ_OK;
 }
@@ -322,6 +333,10 @@ int vlq_line_get_list(vlq_line_t h, int64_t line, uint8_t* codes_out, uint8_t* l
     if (line < 0 || line >= h->nlines) return fail(VLQ_ERR_INVALID, "line id out of range");
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
+    {
+        vlq::ListStore ls = line_store(h);
+        TRY(vlq::lists_sync_host(ls, b->stream));
+    }
     const int64_t o = h->h_line_off[line], len = h->h_line_len[line];
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (len > 0 && codes_out) HIP_TRY(hipMemcpy(codes_out, h->codes.as<uint8_t>() + o * b->M, (size_t)len * b->M, hipMemcpyDeviceToHost));

@@ -2,7 +2,8 @@
 // ids), list i at [off[i], off[i] + len[i]) with capacity off[i+1] - off[i].  Lists loaded
 // with set_lists are packed (capacity == length); lists grown by add() get 25 % slack when
 // the layout has to be rebuilt, so appending is amortised O(batch) and never leaves the
-// device.  Replaces the per-list growable device vectors of the reference
+// device: counts, prefix sums, the overflow test and the new layout are computed there, the host
+// sees one flag and two totals per call.  Replaces the per-list growable device vectors of the reference
 // (gpu/impl/IVFBase.cuh:109-143, gpu/impl/InvertedListAppend.cu:122-247).
 #pragma once
 #include "handle.h"
@@ -17,8 +18,10 @@ struct ListStore {
     DevBuf* ids = nullptr;          // [cap_total] int64
     DevBuf* off = nullptr;          // [nlist+1] int64 list starts (off[nlist] = cap_total)
     DevBuf* len = nullptr;          // [nlist] int64
+    // host copies of off / len for the per-list accessors; *h_stale after a device-side append
     std::vector<int64_t>* h_off = nullptr;
     std::vector<int64_t>* h_len = nullptr;
+    bool* h_stale = nullptr;
 };
 
 typedef AppendWs AppendWorkspace;   // handle.h
@@ -30,8 +33,9 @@ inline void release(AppendWorkspace& w) { w.cnt.release(); w.cstart.release(); w
 // assign32 != nullptr: int32 list ids (VLQ lines) instead of assign64.
 int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* assign64,
                  const int32_t* assign32, const uint8_t* new_codes, const uint8_t* new_lambdas,
-                 const int64_t* xids, int64_t id_base, hipStream_t s);
+                 const int64_t* xids, int64_t id_base, hipStream_t s, int64_t* placed = nullptr);
 
+int lists_sync_host(ListStore& ls, hipStream_t s);
 int lists_relayout(ListStore& ls, std::vector<int64_t>& new_off, hipStream_t s);
 int lists_reserve(ListStore& ls, int64_t num_vecs, hipStream_t s);
 int lists_reclaim(ListStore& ls, uint64_t* bytes, hipStream_t s);
