@@ -1,0 +1,32 @@
+#!/bin/bash
+# Regenerates the inputs of the committed profiles on the GPU box (one gpurun call, from the repo
+# root):  bash profiles/refresh.sh r01   -> gpurun_out/r01/...   then copy the summaries into
+# profiles/ (profiles/collect.py r01).  Counter passes run without tracing domains.
+set -e
+R=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+REPO=$GRAFT_REPO_ROOT
+T="timeout -k 10"
+$T 400 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done" >&2
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+echo "trace done" >&2
+(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc) > $OUT/pmc.log 2>&1
+python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
+echo "pmc done" >&2
+$T 300 python $REPO/tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
+echo "sweep done" >&2
+NBITS=10 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/imi10 -- python $REPO/tools/time_imi.py > $OUT/imi10.log 2>&1
+NBITS=14 NB=20000000 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/imi14 -- python $REPO/tools/time_imi.py > $OUT/imi14.log 2>&1
+NB=16000000 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vlq -- python $REPO/tools/time_vlq.py > $OUT/vlq.log 2>&1
+NB=4000000 $T 300 python $REPO/tools/time_vlq.py > $OUT/vlq4m.log 2>&1
+echo "imi/vlq done" >&2
+{
+  for K in 10 100 256 1000; do K=$K $T 200 python $REPO/tools/long_lists.py 64000000 16384 10000 2>/dev/null | grep -v amdgpu; done
+  for K in 10 100; do DIM=96 NPROBE=128 K=$K $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu; done
+  NPROBE=64 K=10 $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu
+} > $OUT/long_lists.txt
+$T 200 python $REPO/tools/large_k.py 2>/dev/null | grep total > $OUT/large_k.txt
+echo "all done" >&2

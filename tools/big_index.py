@@ -22,8 +22,12 @@ def batch(i, n):
     return (centres[pick] + 0.02 * torch.randn((n, d), generator=gb, device=dev)).contiguous()
 t0 = time.time()
 step = int(os.environ.get('BATCH', 1000000))
+xq = None
 for i in range(0, nb, step):
-    g.add(batch(i // step, min(step, nb - i)))
+    xb = batch(i // step, min(step, nb - i))
+    if xq is None: xq = xb[:nq].clone()           # the first nq database vectors
+    g.add(xb)
+    del xb
     if (i // step) % 10 == 9 or i + step >= nb:
         torch.cuda.synchronize(); print("  added %d M in %.1f s" % ((i + step) // 1000000, time.time() - t0), flush=True)
 torch.cuda.synchronize()
@@ -34,7 +38,6 @@ lens = np.array([g.list_length(i) for i in range(0, nlist, 97)])
 print("sampled list lengths: mean %.1f max %d" % (lens.mean(), lens.max()))
 freed = g.reclaim_memory()
 print("reclaim_memory gave back %.2f GB of append slack" % (freed / 1e9), flush=True)
-xq = batch(0, nq)           # the first nq database vectors
 D = torch.empty((nq, k), dtype=torch.float32, device=dev); I = torch.empty((nq, k), dtype=torch.int64, device=dev)
 for _ in range(2): g.search(xq, nprobe, k, D=D, I=I)
 torch.cuda.synchronize()
