@@ -15,7 +15,11 @@
  * either, gpu/utils/CopyUtils.cuh); device pointers must belong to the index's
  * device.  All work is issued on the index's stream (vlq_ivfpq_set_stream); calls
  * with host output buffers return after the results have landed, calls whose
- * buffers are all device-resident are asynchronous on that stream.
+ * buffers are all device-resident are asynchronous on that stream.  Device inputs
+ * produced on ANOTHER stream must be complete (or that stream must be the index's
+ * stream) before the call: the private stream is non-blocking and does not wait
+ * for the caller's streams -- the reference's GpuResources contract
+ * (gpu/GpuResources.h:36, gpu/StandardGpuResources.cpp).
  *
  * Every function returns VLQ_OK or an error code; vlq_last_error() gives the
  * message of the last failure on the calling thread.  There is no CPU fallback:

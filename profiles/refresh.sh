@@ -11,10 +11,13 @@ REPO=$GRAFT_REPO_ROOT
 T="timeout -k 10"
 $T 400 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done" >&2
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline --no-second-dataset > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done" >&2
-(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc) > $OUT/pmc.log 2>&1
+(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc --no-second-dataset) > $OUT/pmc.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
+# the second data set of bench.py (low intrinsic dimension: little probe overlap between queries)
+(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc2 --no-second-dataset --sigma 0.005 --rank 12 --spread 0.4) > $OUT/pmc2.log 2>&1
+python $REPO/profiles/summarize_pmc.py $OUT/pmc2 > $OUT/pmc2_summary.txt
 echo "pmc done" >&2
 $T 300 python $REPO/tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
 echo "sweep done" >&2

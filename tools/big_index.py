@@ -12,6 +12,7 @@ dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev); gen.manual_seed(5)
 centres = torch.rand((nlist, d), generator=gen, device=dev)
 g = vlq.GpuIVFPQ(d, nlist, M, 8)
+g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 t0 = time.time()
 g.set_coarse_centroids(centres)
 print("set_coarse_centroids (incl. spatial rank of %d lists): %.1f s" % (nlist, time.time() - t0), flush=True)
@@ -47,6 +48,8 @@ for _ in range(5): g.search(xq, nprobe, k, D=D, I=I)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 5
 _n, ncode = g.stats()
-self_hit = float((I[:, 0].cpu().numpy() == np.arange(nq)).mean())
-print("search: %.3f ms per %d queries = %.2f M queries/s, %.0f codes per query, self-hit@1 %.3f" % (
-    dt * 1e3, nq, nq / dt / 1e6, ncode / 5 / nq, self_hit))
+Ih = I.cpu().numpy()
+self_hit = float((Ih[:, 0] == np.arange(nq)).mean())
+self_in = float((Ih == np.arange(nq)[:, None]).any(axis=1).mean())
+print("search: %.3f ms per %d queries = %.2f M queries/s, %.0f codes per query, self-hit@1 %.3f, self in top-%d %.3f" % (
+    dt * 1e3, nq, nq / dt / 1e6, ncode / 5 / nq, self_hit, k, self_in))

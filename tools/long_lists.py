@@ -12,6 +12,7 @@ d, M, nprobe, k = int(os.environ.get("DIM", "128")), 16, int(os.environ.get("NPR
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 g = vlq.GpuIVFPQ(d, nlist, M, 8)
+g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 cent = rng.random((nlist, d), dtype=np.float32)
 g.set_coarse_centroids(cent)
 g.set_pq_centroids(rng.random((M, 256, d // M), dtype=np.float32))

@@ -11,6 +11,7 @@ nbits, nb, nprobe, k, d, M = E("NBITS", 10), E("NB", 4000000), E("NPROBE", 64), 
 nlist = 1 << (2 * nbits)
 rng = np.random.default_rng(0)
 g = vlq.GpuIVFPQ(d, nlist, M, 8)
+g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 imi = rng.random((2, 1 << nbits, d // 2), dtype=np.float32)
 g.set_imi_centroids(nbits, imi)
 g.set_pq_centroids((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2)

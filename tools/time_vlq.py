@@ -14,6 +14,7 @@ d, nlist, nedge, M = E("D", 96), E("NLIST", 4096), E("NEDGE", 16), 16
 nb, nprobe, w1, k = E("NB", 4000000), E("NPROBE", 64), E("W1", 1024), E("K", 128)
 rng = np.random.default_rng(0)
 g = vlq.GpuVLQ(d, nlist, M, 8, nedge, 256)
+g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 cent = rng.random((nlist, d), dtype=np.float32)
 g.set_coarse_centroids(cent)
 g.build_graph()

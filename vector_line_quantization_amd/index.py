@@ -1,6 +1,8 @@
 """Python handle over the C ABI.  Arguments may be numpy arrays (host) or torch
 tensors (host or device: only .data_ptr() is taken -- torch is plumbing for device
-memory and streams, never compute)."""
+memory and streams, never compute).  The library issues its work on the index's own stream:
+hand over device tensors only after the stream that produced them has finished, or make the
+index use that stream (`set_stream(torch.cuda.current_stream().cuda_stream)`)."""
 import ctypes as C
 
 import numpy as np
