@@ -32,7 +32,10 @@ def draw(seed):
                      max_codes=max_codes)
 
 
-@pytest.mark.parametrize("seed", range(40))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VLQ_FUZZ_SEEDS", "40"))))   # VLQ_FUZZ_SEEDS=400 for a soak run
 def test_random_configuration(seed):
     rng, c = draw(seed)
     d, nlist, M, nbits = c["d"], c["nlist"], c["M"], c["nbits"]
