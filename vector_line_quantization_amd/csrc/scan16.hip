@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         uint4 cc = c0, cd = c1;
         prefetch(i + 1);
         __syncthreads();
-        sel.refresh();
+        sel.refresh_with(*wg_thr);
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;

@@ -234,8 +234,12 @@ struct WaveSelect {
     // to f32_to_ordered(FLT_MAX) before any wave flushes)
     __device__ __forceinline__ void attach(uint32_t* w) { wg = w; }
     // pick up the other waves' progress (cheap: one LDS broadcast read)
-    __device__ __forceinline__ void refresh() {
-        const float t = ordered_to_f32(*(volatile uint32_t*)wg) + 0.0f;      // -0 -> +0: nextup(-0) must be > +0
+    __device__ __forceinline__ void refresh() { refresh_with(*(volatile uint32_t*)wg); }
+    // same with the shared word already in hand: a caller that owns the LDS word reads it with a plain
+    // ds_read; through `wg` (a generic pointer) it is a FLAT load whose wait also drains the caller's
+    // outstanding global loads -- fine in the rare flush, not once per probe
+    __device__ __forceinline__ void refresh_with(uint32_t shared_ordered) {
+        const float t = ordered_to_f32(shared_ordered) + 0.0f;      // -0 -> +0: nextup(-0) must be > +0
         thr = __uint_as_float(__builtin_amdgcn_readfirstlane(
             __float_as_uint(fminf(thr_own, ordered_to_f32(f32_to_ordered(t) + 1u)))));
     }
