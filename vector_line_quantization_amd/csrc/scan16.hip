@@ -22,7 +22,9 @@
 
 namespace vlq {
 
-template <int KPL, int NW, int NBUF, bool PIPE>
+// IMI: table type 2 (multi-index: two term2 rows per list) -- a compile-time switch, the row
+// addressing sits in the per-probe prefetch
+template <int KPL, int NW, int NBUF, bool PIPE, bool IMI>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL == 4 || KPL == 2) && PIPE) ? 4 : 1))) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         if (i >= nlive) return;      // (a part may look one probe past its range: harmless loads)
         const int p = ord[i];
         const int64_t key = pm.pkey[p];
-        if (a.imi_nbits > 0) {
+        if (IMI) {
             // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
             // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
             const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
@@ -319,11 +321,16 @@ void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
     else launch_scan16_short_t<16>(a, (int)region, smem, s);
 }
 
+template <int KPL, int NW, int NBUF, bool PIPE, bool IMI>
+static void launch_scan16_i(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE, IMI>), smem);
+    const unsigned grid = (unsigned)(8 * a.xcd_chunk);
+    hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE, IMI>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
+}
 template <int KPL, int NW, int NBUF, bool PIPE>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE>), smem);
-    const unsigned grid = (unsigned)(8 * a.xcd_chunk);
-    hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
+    if (a.imi_nbits > 0) launch_scan16_i<KPL, NW, NBUF, PIPE, true>(a, lut_region, smem, s);
+    else launch_scan16_i<KPL, NW, NBUF, PIPE, false>(a, lut_region, smem, s);
 }
 
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
