@@ -89,10 +89,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
     uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
+    // the prefetched probe's metadata is carried into the iteration that scans it (wave-uniform
+    // values): the loop top has no LDS round trips of its own
+    uint32_t n_len = 0, n_pos0 = 0;
+    float n_dis0 = 0.f;
+    int64_t n_off = 0;
     auto prefetch = [&](int i) {     // i-th probe of the walking order
         if (i >= nlive) return;      // (a part may look one probe past its range: harmless loads)
         const int p = ord[i];
         const int64_t key = pm.pkey[p];
+        n_len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
+        n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
+        n_pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
+        {
+            const int64_t o = pm.poff[p];
+            n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
+                              __builtin_amdgcn_readfirstlane((uint32_t)o));
+        }
         if (IMI) {
             // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
             // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
@@ -108,8 +121,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
             for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
         }
         {   // this thread's first two codes of the list, clamped (branch-free loads)
-            const uint4* cpn = reinterpret_cast<const uint4*>(a.codes) + pm.poff[p];
-            const uint32_t last = pm.plen[p] - 1;
+            const uint4* cpn = reinterpret_cast<const uint4*>(a.codes) + n_off;
+            const uint32_t last = n_len - 1;
             c0 = cpn[min((uint32_t)t, last)];
             c1 = cpn[min((uint32_t)t + NT, last)];
         }
@@ -119,11 +132,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
     int buf = 0;
     uint64_t nscan = 0;
     for (int i = i_begin; i < i_end; i++) {
-        const int ik = ord[i];
-        const uint32_t len = pm.plen[ik];
-        const float dis0 = pm.pd0[ik];
-        const uint32_t pos0 = pm.cum[ik];
-        const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + pm.poff[ik];
+        const uint32_t len = n_len;
+        const float dis0 = n_dis0;
+        const uint32_t pos0 = n_pos0;
+        const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + n_off;
         float* L = lut + buf * E;
         if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
         build_lut16<NI>(L, t, t2r, m2t3);
