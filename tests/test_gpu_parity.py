@@ -361,3 +361,30 @@ def test_merge_topk(k, nparts):
     order = np.argsort(np.where(allI < 0, np.inf, allD), axis=1, kind="stable")[:, :k]
     assert np.array_equal(Do.cpu().numpy(), np.take_along_axis(allD, order, 1))
     assert np.array_equal(Io.cpu().numpy(), np.take_along_axis(allI, order, 1))
+
+
+@pytest.mark.parametrize("nbits,dc,nprobe", [(4, 8, 1), (4, 8, 2), (5, 8, 63), (5, 32, 64), (6, 8, 100), (6, 32, 127),
+                                             (7, 8, 128), (7, 16, 200), (8, 8, 255), (8, 8, 256), (5, 8, 700)])
+def test_multi_index_walk_sizes_and_ties(nbits, dc, nprobe):
+    """MinSumK (IndexPQ.cpp:690-778) replayed on the device (heap in LDS, or in global memory when it
+    does not fit): keys and path-dependent float sums equal to the oracle's replay bit for bit over the
+    heap sizes either side of the switch, with duplicate sub-centroids (equal sums: the heap's own tie
+    order) and both table sources (SSE for 8-dim halves, the distance kernel for wider ones)."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(nbits * 1000 + nprobe)
+    kc, d, M = 1 << nbits, 2 * dc, 4
+    imi = rng.random((2, kc, dc)).astype(np.float32)
+    imi[0, kc // 2:kc // 2 + 3] = imi[0, 1]                   # exact ties between cells
+    imi[1, 5:7] = imi[1, 0]
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    xq = rng.random((37, d)).astype(np.float32)
+    xq[:4, :dc] = imi[0, 1]
+    g = vlq.GpuIVFPQ(d, kc * kc, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, kc * kc, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits)
+    npb = min(nprobe, kc * kc)
+    cd, keys = g.coarse_search(xq, npb)
+    cdo, keyso = ox.coarse_search(xq, npb, canonical=True)
+    assert np.array_equal(keys, keyso)
+    assert np.array_equal(bits(cd), bits(cdo))
