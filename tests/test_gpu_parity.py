@@ -388,3 +388,33 @@ def test_multi_index_walk_sizes_and_ties(nbits, dc, nprobe):
     cdo, keyso = ox.coarse_search(xq, npb, canonical=True)
     assert np.array_equal(keys, keyso)
     assert np.array_equal(bits(cd), bits(cdo))
+
+
+@pytest.mark.parametrize("nlist,d", [(256, 16), (4096, 32), (16384, 8), (320, 12), (131072, 4)])
+def test_nearest_centroid_without_distance_matrix(nlist, d):
+    """nprobe = 1 on >= 20 rows (the assignment of add / encode): the distance kernel emits one
+    (distance, column) key per 64-column tile instead of the matrix.  Same distance bits and the lowest
+    column among exact ties (duplicate centroids inside a tile, across tiles, across row blocks), as the
+    oracle and as the first entry of a wider selection; encode() assigns accordingly."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(nlist + d)
+    M = 4
+    cent = rng.random((nlist, d)).astype(np.float32)
+    cent[nlist // 2:nlist // 2 + 70] = cent[3]                # the nearest centroid of some rows, many copies
+    cent[rng.integers(0, nlist, 40)] = cent[9]
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    xq = rng.random((300, d)).astype(np.float32)
+    xq[:40] = cent[3] + 0.001 * rng.standard_normal((40, d)).astype(np.float32)
+    xq[40:60] = cent[9]
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, M, 8, cent, pq)
+    cd, keys = g.coarse_search(xq, 1)
+    cdo, keyso = ox.coarse_search(xq, 1, canonical=True)
+    assert np.array_equal(keys, keyso)
+    assert np.array_equal(bits(cd), bits(cdo))
+    cd3, keys3 = g.coarse_search(xq, 3)
+    assert np.array_equal(keys3[:, :1], keys) and np.array_equal(bits(cd3[:, :1]), bits(cd))
+    assign, _codes = g.encode(xq)
+    assert np.array_equal(assign, keys[:, 0])

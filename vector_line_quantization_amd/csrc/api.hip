@@ -106,11 +106,14 @@ int64_t query_page(vlq_ivfpq_t h) {
     return page;
 }
 
-// coarse stage of one page; the [n][nlist] distance matrix stays in h->ws_dist
+// coarse stage of one page; keep_matrix: the caller reads the [n][nlist] distance matrix in h->ws_dist
+// afterwards (VLQ line select)
 int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
-                int64_t* keys_dev, bool zero_qnorm, bool direct) {
+                int64_t* keys_dev, bool zero_qnorm, bool direct, bool keep_matrix) {
     TRY(h->ws_qn.reserve((size_t)n * sizeof(float)));
-    TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
+    // 1-NN (assignment): per-tile (distance, column) keys instead of the [n][nlist] matrix
+    const bool argmin = nprobe == 1 && !direct && !keep_matrix && vlq::coarse_argmin_ok(h->nlist, h->d);
+    if (!argmin) TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
     float* tmin = nullptr;
     if (direct) {
         vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
@@ -118,16 +121,22 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
     } else {
         if (zero_qnorm) HIP_TRY(hipMemsetAsync(h->ws_qn.p, 0, (size_t)n * sizeof(float), h->stream));
         else vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
-        if (vlq::coarse_tile_minima_ok(h->nlist, h->d, nprobe)) {
+        if (argmin) {
+            TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * 8));
+            tmin = h->ws_tmin.as<float>();
+        } else if (vlq::coarse_tile_minima_ok(h->nlist, h->d, nprobe)) {
             TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * sizeof(float)));
             tmin = h->ws_tmin.as<float>();
         }
         vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(),
-                                     h->cnorm.as<float>(), h->ws_dist.as<float>(), n, h->nlist,
-                                     h->d, h->stream, tmin);
+                                     h->cnorm.as<float>(), argmin ? nullptr : h->ws_dist.as<float>(), n,
+                                     h->nlist, h->d, h->stream, tmin);
     }
-    vlq::launch_coarse_select(h->ws_dist.as<float>(), n, h->nlist, nprobe, cdis_dev, keys_dev,
-                              h->stream, tmin);
+    if (argmin)
+        vlq::launch_coarse_argmin(tmin, n, h->nlist, cdis_dev, keys_dev, h->stream);
+    else
+        vlq::launch_coarse_select(h->ws_dist.as<float>(), n, h->nlist, nprobe, cdis_dev, keys_dev,
+                                  h->stream, tmin);
     HIP_TRY(hipGetLastError());
     return VLQ_OK;
 }
@@ -157,6 +166,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     for (int m = 0; m < 2; m++) {
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
         float* tmin = nullptr;
+        bool argmin = false;
         if (dc < 16) {
             // compute_distance_table (ProductQuantizer.cpp:410-422): fvec_L2sqr per entry
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
@@ -166,14 +176,19 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
             TRY(h->ws_qn.reserve((size_t)n * 4));
             vlq::launch_row_norms(sub, n, dc, h->ws_qn.as<float>(), h->stream);
-            if (vlq::coarse_tile_minima_ok(kc, dc, T)) {
+            argmin = T == 1 && vlq::coarse_argmin_ok(kc, dc);
+            if (argmin) {
+                TRY(h->ws_tmin.reserve((size_t)n * (kc / 64) * 8));
+                tmin = h->ws_tmin.as<float>();
+            } else if (vlq::coarse_tile_minima_ok(kc, dc, T)) {
                 TRY(h->ws_tmin.reserve((size_t)n * (kc / 64) * sizeof(float)));
                 tmin = h->ws_tmin.as<float>();
             }
             vlq::launch_coarse_distances(sub, cent, h->ws_qn.as<float>(), h->imi_norm.as<float>() + (size_t)m * kc,
-                                         tab[m], n, kc, dc, h->stream, tmin);
+                                         argmin ? nullptr : tab[m], n, kc, dc, h->stream, tmin);
         }
-        vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
+        if (argmin) vlq::launch_coarse_argmin(tmin, n, kc, sv[m], si[m], h->stream);
+        else vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
     }
     vlq::launch_imi_minsum(sv[0], si[0], sv[1], si[1], T, n, k, kc, h->imi_nbits, hv, hi, cdis_dev, keys_dev,
                            h->stream);
@@ -194,9 +209,10 @@ int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* 
         tm.stop();
         return VLQ_OK;
     }
-    const int64_t page = query_page(h);
     // knn_L2sqr dispatch (utils.cpp:935-946): small batches bypass the GEMM formulation
     const bool direct = (h->d % 4 == 0) && n < 20;
+    // a 1-NN assignment writes no distance matrix: full pages whatever nlist is
+    const int64_t page = (nprobe == 1 && !direct && vlq::coarse_argmin_ok(h->nlist, h->d)) ? 32768 : query_page(h);
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
         TRY(coarse_page(h, ni, x_dev + i0 * h->d, nprobe, cdis_dev + i0 * nprobe,

@@ -125,8 +125,9 @@ int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t by
                    void* I, const void* Id, size_t bytesI);
 int ensure_term2(vlq_ivfpq_t h);
 int64_t query_page(vlq_ivfpq_t h);
-// coarse stage of ONE page (n <= query_page): leaves the [n][nlist] distance matrix in
-// h->ws_dist; zero_qnorm drops |q|^2 (the VLQ path, impl/Distance.cu:286-291)
+// coarse stage of ONE page (n <= query_page); keep_matrix: the [n][nlist] distance matrix must be
+// left in h->ws_dist (the VLQ line select reads it) -- a 1-NN assignment otherwise never writes it;
+// zero_qnorm drops |q|^2 (the VLQ path, impl/Distance.cu:286-291)
 int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
-                int64_t* keys_dev, bool zero_qnorm, bool direct);
+                int64_t* keys_dev, bool zero_qnorm, bool direct, bool keep_matrix = false);
 }  // namespace vlq_detail

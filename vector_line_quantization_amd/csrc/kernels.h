@@ -21,6 +21,10 @@ void launch_coarse_distances(const float* q, const float* c, const float* qn, co
                              float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin = nullptr);
 // wide rows and few probes: the distance kernel can hand the select a [nq][nlist/64] matrix of tile minima
 bool coarse_tile_minima_ok(int nlist, int d, int nprobe);
+// 1-NN (the assignment of add / encode): out == nullptr and tmin = [nq][nlist / 64] 64-bit keys -- the
+// distance kernel writes no matrix, launch_coarse_argmin reduces the keys to (distance, centroid)
+bool coarse_argmin_ok(int nlist, int d);
+void launch_coarse_argmin(const void* tile_keys, int64_t nq, int nlist, float* cdis, int64_t* keys, hipStream_t s);
 
 // < 20 queries: direct fvec_L2sqr per pair (utils.cpp:757-786)
 void launch_coarse_distances_direct(const float* q, const float* c, float* out, int64_t nq,

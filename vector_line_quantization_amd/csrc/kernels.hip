@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(
 // j is multiplied and written to the other buffer afterwards; one barrier per tile.
 // Same k order (0,1,2,...) and epilogue as coarse_dist_kernel -> identical bits.
 // ---------------------------------------------------------------------------
-// TMIN (nlist % 64 == 0): also writes tmin[row][tile] = the minimum of the row's 64 distances in
+// TMIN == 1 (nlist % 64 == 0): also writes tmin[row][tile] = the minimum of the row's 64 distances in
 // that column tile -- 1/64 of the matrix -- from which coarse_select_tiled_kernel finds the few
 // tiles that can hold one of the nprobe nearest centroids and reads only those.
-template <int NU, bool VEC, bool TMIN>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
+// TMIN == 3 (1-NN: the assignment of add / encode): NO matrix; per (row, tile) one 64-bit key
+// ordered(distance) << 32 | column of the tile's (distance, column) minimum -- the total order of
+// wave_topk.cuh -- so the nearest centroid of a row is the minimum of its nlist / 64 keys.
+template <int NU, bool VEC, int TMIN>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
 __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
     const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d,
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         // 4x fewer store instructions than dword stores, which were issue-bound.
         const bool full = (tile * 64 + 64 <= nlist) && ((nlist & 3) == 0);
         float mrow[4];
+        u64 krow[4];
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
             const int col = tile * 64 + tj * 32 + r;
@@ -329,12 +333,20 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                     }
                     // lane (r = 4q + i, h): row 8g + 4h + i, columns 4q .. 4q+3
                     const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + (r & 3);
-                    if (row < nq)
+                    if (TMIN != 3 && row < nq)
                         *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) =
                             make_float4(v[0], v[1], v[2], v[3]);
-                    if (TMIN) {
+                    if (TMIN == 1) {
                         const float m4 = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
                         mrow[g] = tj == 0 ? m4 : fminf(mrow[g], m4);
+                    }
+                    if (TMIN == 3) {
+                        const uint32_t c0 = (uint32_t)(tile * 64 + tj * 32 + (r & ~3));
+                        u64 kk = make_key(v[0], c0);
+                        kk = umin64(kk, make_key(v[1], c0 + 1));
+                        kk = umin64(kk, make_key(v[2], c0 + 2));
+                        kk = umin64(kk, make_key(v[3], c0 + 3));
+                        krow[g] = tj == 0 ? kk : umin64(krow[g], kk);
                     }
                 } else {
 #pragma unroll
@@ -345,7 +357,18 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                 }
             }
         }
-        if (TMIN) {
+        if (TMIN == 3) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                u64 kk = krow[g];
+                kk = umin64(kk, shfl_xor_u64(kk, 4));
+                kk = umin64(kk, shfl_xor_u64(kk, 8));
+                kk = umin64(kk, shfl_xor_u64(kk, 16));
+                const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + r;
+                if (r < 4 && row < nq) reinterpret_cast<u64*>(tmin)[row * (nlist >> 6) + tile] = kk;
+            }
+        }
+        if (TMIN == 1) {
             // lane (r = 4q + i, h) holds row 8g + 4h + i, columns 4q..4q+3 of both halves: the row's
             // tile minimum is the minimum over q, i.e. over lane bits 2..4
 #pragma unroll
@@ -375,11 +398,11 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     }
 }
 
-template <int NU, bool VEC, bool TMIN>
+template <int NU, bool VEC, int TMIN>
 static void launch_coarse_areg_t(const float* q, const float* c, const float* qn, const float* cn,
                                float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
     constexpr int S = 4 * NU + 4;
-    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN ? (size_t)4 * 32 * 17 * sizeof(float) : 0);
+    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN == 1 ? (size_t)4 * 32 * 17 * sizeof(float) : 0);
     ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC, TMIN>), smem);
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
@@ -401,15 +424,47 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
 template <int NU>
 static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
                                float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
-    if (tmin) launch_coarse_areg_t<NU, true, true>(q, c, qn, cn, out, nq, nlist, d, tmin, s);   // coarse_tile_minima_ok
-    else if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true, false>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
-    else launch_coarse_areg_t<NU, false, false>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
+    if (tmin && !out) launch_coarse_areg_t<NU, true, 3>(q, c, qn, cn, out, nq, nlist, d, tmin, s);   // coarse_argmin_ok
+    else if (tmin) launch_coarse_areg_t<NU, true, 1>(q, c, qn, cn, out, nq, nlist, d, tmin, s);       // coarse_tile_minima_ok
+    else if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true, 0>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
+    else launch_coarse_areg_t<NU, false, 0>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
 }
 
 // tile minima are produced by the d <= 128 kernels for whole 64-column tiles and 16-byte row loads
 bool coarse_tile_minima_ok(int nlist, int d, int nprobe) {
     return d <= 128 && d >= 4 && d % 4 == 0 && nlist % 64 == 0 && nlist > 8192 && nlist <= 2048 * 64 &&
            nlist / 64 >= 4 * nprobe;
+}
+
+// 1-NN without a distance matrix (out == nullptr, tmin = [nq][nlist / 64] 64-bit keys)
+bool coarse_argmin_ok(int nlist, int d) {
+    return d <= 128 && d >= 4 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256;
+}
+
+// nearest centroid of every row from the per-tile keys of the TMIN == 3 distance kernel
+__global__ __launch_bounds__(256) void coarse_argmin_kernel(const u64* __restrict__ tkeys, int64_t nq, int ntiles,
+                                                            float* __restrict__ cdis, int64_t* __restrict__ keys) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const u64* row = tkeys + q * ntiles;
+    u64 best = kMaxKey;
+    for (int j = lane; j < ntiles; j += 64) best = umin64(best, row[j]);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) best = umin64(best, shfl_xor_u64(best, sft));
+    if (lane == 0) {
+        const float dis = ordered_to_f32((uint32_t)(best >> 32));
+        // the reference's heap starts at FLT_MAX and admits only dis < top (Heap.h:76-78)
+        const bool miss = !(dis < FLT_MAX_F);
+        cdis[q] = miss ? FLT_MAX_F : dis;
+        keys[q] = miss ? -1 : (int64_t)(uint32_t)best;
+    }
+}
+
+void launch_coarse_argmin(const void* tkeys, int64_t nq, int nlist, float* cdis, int64_t* keys, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(coarse_argmin_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s,
+                       reinterpret_cast<const u64*>(tkeys), nq, nlist >> 6, cdis, keys);
 }
 
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,

@@ -38,7 +38,7 @@ int assign_dev(vlq_line_t h, int64_t n, const float* xd) {
     TRY(h->ws_line.reserve((size_t)n * 4));
     TRY(h->ws_lamf.reserve((size_t)n * 4));
     TRY(b->ws_misc.reserve((size_t)n * 4));
-    const int64_t page = query_page(b);
+    const int64_t page = vlq::coarse_argmin_ok(b->nlist, b->d) ? 32768 : query_page(b);   // 1-NN: no distance matrix
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
         // quantizer 1-NN with true distances (classifyAndAddVectors: query(vecs, 1, ..., true))
@@ -379,7 +379,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         const int64_t ni = std::min(page, n - i0);
         const float* xi = (const float*)xd + i0 * b->d;
         // 1. all centroid "distances" without |q|^2 + the nprobe nearest (Distance.cu:233-383)
-        TRY(coarse_page(b, ni, xi, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false));
+        TRY(coarse_page(b, ni, xi, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false, true));
         // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
         int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
         vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
