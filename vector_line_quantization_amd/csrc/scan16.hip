@@ -84,7 +84,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
 
     WaveSelect<KPL, QR, KPL >= 2> sel;   // k > 64: the merge network stays out of the scan loop's register budget
     sel.init(a.k, queue + wave * 64 * QR, lane);
-    sel.attach(wg_thr);
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
@@ -142,6 +141,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         uint4 cc = c0, cd = c1;
         prefetch(i + 1);
         __syncthreads();
+        if (sel.dirty) {     // wave-uniform: publish this wave's k-th distance, then take the workgroup's minimum
+            if (lane == 0) atomicMin(wg_thr, f32_to_ordered(sel.thr_own));
+            sel.dirty = false;
+        }
         sel.refresh_with(*wg_thr);
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
@@ -200,7 +203,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         if (NBUF == 2) buf ^= 1;
     }
 
-    sel.attach(nullptr);
     merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                         [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);

@@ -155,11 +155,14 @@ __device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
 template <int KPL>
 struct BestList { u64 v[KPL]; float kth; };
 
+// (the parked keys travel by value too: read through the callee's generic pointer they were FLAT
+// loads whose wait drained the caller's outstanding global prefetches at every flush)
+template <int QR>
+struct Pending { u64 v[QR]; };
+
 template <int KPL, int QR>
-__device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, const u64* queue, int npend, int k, int lane) {
-    u64 p[QR];
-#pragma unroll
-    for (int r = 0; r < QR; r++) p[r] = (r * 64 + lane < npend) ? queue[r * 64 + lane] : kMaxKey;
+__device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, Pending<QR> pend, int k, int lane) {
+    u64 (&p)[QR] = pend.v;
     wave_sort_multi<QR>(p, lane);
     // pending reversed (element e -> N-1-e) against the tail of the best list: bitonic split
 #pragma unroll
@@ -179,8 +182,8 @@ __device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, const u64* 
     return b;
 }
 template <int KPL, int QR>
-__device__ __noinline__ BestList<KPL> flush_call(BestList<KPL> b, const u64* queue, int npend, int k, int lane) {
-    return flush_body<KPL, QR>(b, queue, npend, k, lane);
+__device__ __noinline__ BestList<KPL> flush_call(BestList<KPL> b, Pending<QR> pend, int k, int lane) {
+    return flush_body<KPL, QR>(b, pend, k, lane);
 }
 
 template <int KPL, int QR = 1, bool OUTLINE = false>
@@ -193,19 +196,24 @@ struct WaveSelect {
     int k;
     int lane;
     u64* queue;
-    // Optional LDS word shared by the waves of a workgroup that select from disjoint parts of ONE
-    // stream (their lists are merged afterwards): the minimum of their k-th distances, as its
-    // ordered image.  A wave whose k-th best is T holds k keys with distance <= T, so a candidate of
-    // ANOTHER wave can still reach the merged top-k only if dis <= T.  `dis <= T` is `dis <
-    // nextup(T)`, so the hot loop keeps its one strict compare.  The own threshold stays strict
-    // (min(thr_own, nextup(T)) == thr_own when T == thr_own).
-    uint32_t* wg;
+    // Optional bound shared by the waves of a workgroup that select from disjoint parts of ONE stream
+    // (their lists are merged afterwards): the minimum of their k-th distances.  A wave whose k-th
+    // best is T holds k keys with distance <= T, so a candidate of ANOTHER wave can still reach the
+    // merged top-k only if dis <= T.  `dis <= T` is `dis < nextup(T)`, so the hot loop keeps its one
+    // strict compare; the own threshold stays strict (min(thr_own, nextup(T)) == thr_own when
+    // T == thr_own).  The selection itself never touches the shared word (through a generic pointer
+    // that is a FLAT access whose wait also drains the caller's outstanding global loads): the owner
+    // of the word -- the kernel, with plain LDS instructions -- publishes `thr_own` when `dirty` and
+    // hands the current minimum to refresh_with().
+    float thr_sh;     // nextup of the last shared minimum seen (+inf: none)
+    bool dirty;       // thr_own changed since the caller last published it
 
     __device__ __forceinline__ void init(int k_, u64* queue_, int lane_) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) best[r] = kMaxKey;
         thr = thr_own = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
-        wg = nullptr;
+        thr_sh = __builtin_inff();
+        dirty = false;
         npend = 0;
         k = k_;
         lane = lane_;
@@ -218,30 +226,24 @@ struct WaveSelect {
         BestList<KPL> b;
 #pragma unroll
         for (int r = 0; r < KPL; r++) b.v[r] = best[r];
-        b = OUTLINE ? flush_call<KPL, QR>(b, queue, npend, k, lane) : flush_body<KPL, QR>(b, queue, npend, k, lane);
+        Pending<QR> pend;
+#pragma unroll
+        for (int r = 0; r < QR; r++) pend.v[r] = (r * 64 + lane < npend) ? queue[r * 64 + lane] : kMaxKey;
+        b = OUTLINE ? flush_call<KPL, QR>(b, pend, k, lane) : flush_body<KPL, QR>(b, pend, k, lane);
 #pragma unroll
         for (int r = 0; r < KPL; r++) best[r] = b.v[r];
         npend = 0;
         // (wave-uniform: keep it in a scalar register)
-        thr = thr_own = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b.kth)));
-        if (wg) {
-            if (lane == 0) atomicMin(wg, f32_to_ordered(thr_own));
-            refresh();
-        }
+        thr_own = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b.kth)));
+        thr = fminf(thr_own, thr_sh);
+        dirty = true;
     }
 
-    // share thresholds with the other waves of the workgroup through *w (initialised by the caller
-    // to f32_to_ordered(FLT_MAX) before any wave flushes)
-    __device__ __forceinline__ void attach(uint32_t* w) { wg = w; }
-    // pick up the other waves' progress (cheap: one LDS broadcast read)
-    __device__ __forceinline__ void refresh() { refresh_with(*(volatile uint32_t*)wg); }
-    // same with the shared word already in hand: a caller that owns the LDS word reads it with a plain
-    // ds_read; through `wg` (a generic pointer) it is a FLAT load whose wait also drains the caller's
-    // outstanding global loads -- fine in the rare flush, not once per probe
+    // the workgroup's current minimum (ordered image), read by the caller
     __device__ __forceinline__ void refresh_with(uint32_t shared_ordered) {
         const float t = ordered_to_f32(shared_ordered) + 0.0f;      // -0 -> +0: nextup(-0) must be > +0
-        thr = __uint_as_float(__builtin_amdgcn_readfirstlane(
-            __float_as_uint(fminf(thr_own, ordered_to_f32(f32_to_ordered(t) + 1u)))));
+        thr_sh = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ordered_to_f32(f32_to_ordered(t) + 1u))));
+        thr = fminf(thr_own, thr_sh);
     }
 
     // one candidate per lane (`valid` lanes only); wave-uniform control flow.
