@@ -393,8 +393,7 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    h->h_list_off.assign((size_t)nlist + 1, 0);
-    h->h_list_len.assign((size_t)nlist, 0);
+    h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
     int rc = h->stats.reserve(16);
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
     if (rc == VLQ_OK) rc = h->list_len.reserve((size_t)nlist * 8);

@@ -97,8 +97,7 @@ int vlq_line_create(vlq_line_t* out, int device, int d, int nlist, int M, int nb
     int rc = vlq_ivfpq_create(&h->base, device, d, nlist, M, nbits);
     if (rc != VLQ_OK) { delete h; return rc; }
     h->nedge = nedge; h->nlambda = nlambda; h->nlines = (int64_t)nlist * nedge;
-    h->h_line_off.assign((size_t)h->nlines + 1, 0);
-    h->h_line_len.assign((size_t)h->nlines, 0);
+    h->h_lines_stale = true;    // host copies are filled on first use
     rc = h->line_off.reserve(((size_t)h->nlines + 1) * 8);
     if (rc == VLQ_OK) rc = h->line_len.reserve((size_t)h->nlines * 8);
     if (rc == VLQ_OK) rc = h->stats.reserve(16);
