@@ -151,3 +151,39 @@ def test_many_lists_deep1b_shape():
     # and a vector finds itself
     Ds, Is = g.search(xb[:64], nprobe, 1)
     assert (Is[:, 0] == np.arange(64)).mean() > 0.9
+
+
+@pytest.mark.parametrize("k", [10, 100, 200])
+def test_long_lists_wide_rows_vs_oracle(k):
+    """Deep1B-like proportions at a size the oracle finishes in seconds: 16 384 lists (two-level coarse
+    select from tile minima, 1-NN assignment without a matrix), lists of ~3000 codes (pipelined loop for
+    every selection class), d = 96 (dsub = 6), 2 M codes with runs of identical codes (exact ties across
+    chunks and waves).  Distances and labels equal to the oracle's canonical order on a query sample."""
+    rng = np.random.default_rng(99 + k)
+    d, nlist, M_, nb, nq, nprobe = 96, 16384, 16, 2000000, 2000, 24
+    coarse = rng.random((nlist, d), dtype=np.float32)
+    pq = (rng.random((M_, 256, d // M_), dtype=np.float32) - 0.5) * 0.2
+    hot = rng.choice(nlist, 640, replace=False)                       # the codes sit in 640 lists
+    lens = np.zeros(nlist, np.int64)
+    lens[hot] = rng.multinomial(nb, np.full(640, 1.0 / 640))
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    codes = rng.integers(0, 256, (nb, M_), dtype=np.uint8)
+    codes[5000:5600] = codes[5000]
+    ids = rng.permutation(nb).astype(np.int64)
+    xq = (coarse[rng.choice(hot, nq)] + 0.02 * rng.standard_normal((nq, d))).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M_, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    g.set_lists(codes, ids, off)
+    assert g.ntotal >= 1024 * 640
+    D, I = g.search(xq, nprobe, k)
+    sel = np.arange(0, nq, 67)
+    ox = pyoracle.OracleIndex(d, nlist, M_, 8, coarse, pq, codes=codes, ids=ids, list_offsets=off)
+    Do, Io = ox.search(xq[sel], nprobe, k, canonical=True)
+    assert np.array_equal(bits(D[sel]), bits(Do))
+    assert np.array_equal(I[sel], Io)
+    # the assignment path (no distance matrix) agrees with the first probe of the search path
+    assign, _c = g.encode(xq[:400])
+    _cd, keys = g.coarse_search(xq[:400], nprobe)
+    assert np.array_equal(assign, keys[:, 0])
