@@ -1,5 +1,6 @@
 #!/bin/bash
-# args: out_dir K
+# PMC counters of scan16_kernel on long lists for one k (kernel experiments; counters only, no tracing
+# domains):   bash tools/pmc_k.sh <out_dir under gpurun_out> <k>   on the GPU box, from the repo root
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export K=$2
