@@ -99,9 +99,10 @@ int check_ready(vlq_ivfpq_t h, bool need_lists) {
 
 int64_t query_page(vlq_ivfpq_t h) {
     // GpuIndex::search pages at 32768 queries (gpu/GpuIndex.cu:29,108-147); also keep the
-    // [page][nlist] distance matrix under 1 GiB
+    // [page][nlist] distance matrix under 8 GiB (sized for 288 GB of HBM: at 2^17 lists a 10 000-query
+    // batch is one 5.2 GB page; 1 GiB pages cost the coarse stage 15 % there)
     int64_t page = 32768;
-    int64_t by_mat = (int64_t)((size_t(1) << 28) / (size_t)std::max(1, h->nlist));
+    int64_t by_mat = (int64_t)((size_t(1) << 31) / (size_t)std::max(1, h->nlist));
     page = std::max<int64_t>(1, std::min(page, by_mat));
     return page;
 }
@@ -201,7 +202,7 @@ int coarse_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* 
     StageTimer tm(h, 0);
     if (h->imi_nbits > 0) {
         const int64_t kc = int64_t(1) << h->imi_nbits;
-        const int64_t page = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)((size_t(1) << 27) / (size_t)kc)));
+        const int64_t page = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)((size_t(1) << 29) / (size_t)kc)));
         for (int64_t i0 = 0; i0 < n; i0 += page) {
             const int64_t ni = std::min(page, n - i0);
             TRY(imi_page(h, ni, x_dev + i0 * h->d, nprobe, cdis_dev + i0 * nprobe, keys_dev + i0 * nprobe));
