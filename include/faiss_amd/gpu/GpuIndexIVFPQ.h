@@ -23,7 +23,7 @@ struct GpuIndexConfig {
 };
 struct GpuIndexFlatConfig : public GpuIndexConfig {
   GpuIndexFlatConfig() : useFloat16(false), useFloat16Accumulator(false), storeTransposed(false) {}
-  bool useFloat16;              ///< must stay false: the path computes in fp32 (parity with the CPU index)
+  bool useFloat16;              ///< accepted; the coarse quantizer stays fp32 here (superset precision)
   bool useFloat16Accumulator;
   bool storeTransposed;         ///< layout hint of the reference's cuBLAS call; no effect here
 };
@@ -34,7 +34,7 @@ struct GpuIndexIVFConfig : public GpuIndexConfig {
 };
 struct GpuIndexIVFPQConfig : public GpuIndexIVFConfig {
   GpuIndexIVFPQConfig() : useFloat16LookupTables(false), usePrecomputedTables(false) {}
-  bool useFloat16LookupTables;  ///< must stay false (fp32 LUT, bit parity)
+  bool useFloat16LookupTables;  ///< accepted; tables stay fp32 here (superset precision, bit parity with the CPU index)
   bool usePrecomputedTables;
 };
 
@@ -181,6 +181,8 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, enable ? 1 : 0, 0));
   }
   bool getPrecomputedCodes() const { return usePrecomputed_; }
+  /// what the caller asked for (the tables themselves are fp32 here, see verifyConfig_)
+  bool getFloat16LookupTables() const { return ivfpqConfig_.useFloat16LookupTables; }
   int getNumSubQuantizers() const { return subQuantizers_; }
   int getBitsPerCode() const { return bitsPerCode_; }
   int getCentroidsPerSubQuantizer() const { return 1 << bitsPerCode_; }
@@ -413,9 +415,17 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_line_set_pq_centroids(line_, pqCentroids_.data()));
     is_trained = true;
   }
+  // The reference's own drivers ask for float16 look-up tables / coarse storage
+  // (gpu/test/deep1b16_query.cpp:239-243: co.useFloat16 = true -> config.useFloat16LookupTables), a
+  // speed/memory option of its CUDA kernels (gpu/GpuIndexIVFPQ.h:24-38, impl/IVFPQ.cu:1442 toHalf).
+  // They are ACCEPTED and recorded; this library computes the same quantities in fp32 -- every result
+  // the fp16 configuration could return is returned at higher precision, and the fp32 path is the one
+  // pinned bit for bit to the CPU index.  Only options that would change SEMANTICS are rejected.
   void verifyConfig_() const {
-    FAISS_THROW_IF_NOT_MSG(!ivfpqConfig_.useFloat16LookupTables && !ivfpqConfig_.flatConfig.useFloat16,
-                           "float16 tables/storage are not built: the path is fp32 for bit parity with the CPU index");
+    FAISS_THROW_IF_NOT_MSG(ivfpqConfig_.memorySpace == MemorySpace::Device || ivfpqConfig_.memorySpace == MemorySpace::Unified,
+                           "unknown memory space");
+    FAISS_THROW_IF_NOT_MSG(ivfpqConfig_.indicesOptions >= INDICES_CPU && ivfpqConfig_.indicesOptions <= INDICES_64_BIT,
+                           "unknown indicesOptions");
   }
   void create_() {
     VLQ_CHECK(vlq_ivfpq_create(&h_, device_, d, nlist_, subQuantizers_, bitsPerCode_));

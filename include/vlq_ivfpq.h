@@ -120,7 +120,11 @@ int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k
 
 /* The parity seam: IndexIVFPQ::search_knn_with_key (IndexIVFPQ.h:140-146,
  * IndexIVFPQ.cpp:964-1060).  keys[n*nprobe] (-1 = skip), coarse_dis[n*nprobe].
- * store_pairs != 0 returns list<<32|offset as label.  All buffers [h|d]. */
+ * store_pairs != 0 returns list<<32|offset as label.  All buffers [h|d].
+ * A key >= nlist aborts the reference's search (IndexIVFPQ.cpp:1008-1011): with a host D or I
+ * the call synchronises and returns VLQ_ERR_INVALID itself; with device D and I the call stays
+ * asynchronous, the offending probe is skipped and the error is returned by the next
+ * vlq_ivfpq_stats() (which also clears it). */
 int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* keys,
                                  const float* coarse_dis, int nprobe, int k, float* D,
                                  int64_t* I, int store_pairs);

@@ -158,14 +158,28 @@ static inline bool vless(const VCand& a, const VCand& b) { return a.dis < b.dis 
 //  2. line select (sumAlongRowsWithOrder2, impl/BroadcastSum.cu:477-560): candidate i =
 //     rank*nedge + e over the nprobe centroids x their edges; a2 = v[s], b2 = v[c],
 //     c2 = edge length, g = a2 - b2, t = g - c2, key = t > 0 ? b2 : b2 - 0.25*t*t/c2;
-//     the w1 smallest (key, i).
+//     the w1 smallest (key, i), emitted in that (ascending) order (:538-553).
 //  3. scan (pqScanPrecomputedMultiPassGraph, impl/PQScanMultiPassPrecomputed.cu:675-811):
-//     per selected line (c, s), at most 1024 codes (:728); per code with l = lambda_info[byte]
-//        dist = ((b2 + l*g) + (l*l - l)*c2) + S23 + l*S4
-//        S23 = sum_m (term2[c][m][code_m] + (-2)<q_m, cent_m,code_m>)   (left to right from 0)
-//        S4  = sum_m (term2[s][m][code_m] - term2[c][m][code_m])         (left to right from 0)
+//     per selected line (c, s), at most 1024 codes (:728); per code with l = lambda_info[byte],
+//     in the order the source writes it (:783-811):
+//        dist = (b2 + l*g) + (l*l - l)*c2
+//        dist += T23[m][code_m], m = 0..M-1   with T23 = term2[c] + (-2)<q_m, cent>  (:54-75)
+//        tmp  += T4[m][code_m]  (from 0)      with T4  = term2[s] - term2[c]          (:313-334)
+//        out = dist + l*tmp
 //  4. the k smallest (dist, scan position) with the heap's strict-< admission against
-//     FLT_MAX; labels are the stored ids.
+//     FLT_MAX; labels are the stored ids.  Scan position = offset in the reference's output
+//     array: lines in their emitted (ascending key) order, codes in list order.
+//
+// ORDER CHOICES this file makes where the CUDA source leaves them open (every one is also what the
+// HIP kernels do, bit for bit):
+//   a. every a*b+c is an unfused multiply then add (nvcc's default -fmad=true would contract some of
+//      them; which ones is a compiler decision, so the written operator order is followed instead);
+//   b. the coarse inner product is a k-ascending fmaf chain (the reference calls cuBLAS);
+//      <q_m, cent> of term3 likewise is the IVFPQ oracle's SSE-order inner product (cuBLAS there);
+//   c. |x - c|^2 of the assignment is the SSE-order sum (the reference tree-reduces across a block);
+//   d. equal keys: lowest candidate index in the line select, lowest edge in the assignment, first
+//      minimum in the lambda quantiser, lowest scan position in the final top-k (the reference's
+//      bitonic3 / BlockSelect leave ties unspecified).
 // Returns the number of codes visited.
 int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe, int w1, int k,
                        float* D, int64_t* I, int32_t* lines_out /* [nq][w1] or NULL */) {
@@ -209,10 +223,10 @@ int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe
                 }
             }
             const int nw = std::min<int>(w1, (int)lines.size());
+            // the kept lines are emitted -- and therefore laid out in the scan's output array
+            // (prefixSumOffsets, PQScanMultiPassPrecomputed.cu:711-712) -- in ascending key order
+            // (BroadcastSum.cu:538-553: the sorted heap contents); scan positions follow this order
             std::partial_sort(lines.begin(), lines.begin() + nw, lines.end(), vless);
-            // the kept lines are walked in candidate order (probe rank, edge): lines that share
-            // their anchor centroid are neighbours, and scan positions (ties) follow this order
-            std::sort(lines.begin(), lines.begin() + nw, [](const VCand& a, const VCand& b) { return a.pos < b.pos; });
             for (int m = 0; m < ix->M; m++)
                 for (int j = 0; j < ix->ksub; j++)
                     t3[m * ix->ksub + j] = -2.0f * orc_fvec_inner_product(
@@ -232,13 +246,17 @@ int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe
                 for (int64_t jj = 0; jj < len; jj++) {
                     const uint8_t* code = ix->codes + (size_t)(o + jj) * ix->M;
                     const float l = ix->lambda_info[ix->lambdas[o + jj]];
-                    float s23 = 0.f, s4 = 0.f;
+                    // PQScanMultiPassPrecomputed.cu:783-811, in the order written:
+                    //   dist = term1 + la*term6 + (la*la-la)*term5;  dist += term23[m] (m ascending);
+                    //   tmp += term4[m];  out = dist + la*tmp
+                    float dist = (b2 + l * g) + (l * l - l) * c2;
+                    float tmp = 0.f;
                     for (int m = 0; m < ix->M; m++) {
                         const size_t idx = (size_t)m * ix->ksub + code[m];
-                        s23 += t2c[idx] + t3[idx];
-                        s4 += t2s[idx] - t2c[idx];
+                        dist += t2c[idx] + t3[idx];          // term23 entry (loadPrecomputedTerm :54-75)
+                        tmp += t2s[idx] - t2c[idx];          // term4 entry (loadPrecomputedTermGraph :313-334)
                     }
-                    const float dist = (((b2 + l * g) + (l * l - l) * c2) + s23) + l * s4;
+                    dist = dist + l * tmp;
                     if (dist < FLT_MAX) res.push_back({dist, pos + jj, ix->ids[o + jj]});
                 }
                 pos += len;

@@ -9,6 +9,7 @@
 
 #include "faiss_amd/IndexFlat.h"
 #include "faiss_amd/IndexIVFPQ.h"
+#include "faiss_amd/gpu/GpuClonerOptions.h"
 #include "faiss_amd/gpu/GpuIndexIVFPQ.h"
 #include "faiss_amd/gpu/StandardGpuResources.h"
 #include "faiss_amd/index_io.h"
@@ -150,6 +151,52 @@ int main() {
       for (int j = 0; j < d; j++) qn += (double)queries[q * d + j] * queries[q * d + j];
       EXPECT(vdis[q * k] + qn > -1e-3);
     }
+  }
+
+  // part 2e: the configuration block of the reference's VLQ drivers, as they write it
+  // (gpu/test/deep1b16_query.cpp:224-243; gpu/test/sift1b16_query.cpp likewise): float16 look-up
+  // tables requested through GpuClonerOptions, ids "on the CPU", a temp-memory fraction.  It must
+  // construct, train, add and search -- and, because this library computes the requested fp16
+  // quantities in fp32, answer exactly like the default configuration.
+  {
+    faiss::gpu::StandardGpuResources resources;
+    resources.setTempMemoryFraction(0.25);
+    int dev_no = 0;
+    faiss::gpu::GpuIndexIVFPQConfig cfg16;
+    cfg16.device = dev_no;
+    faiss::gpu::GpuClonerOptions co;
+    co.useFloat16 = true;
+    cfg16.indicesOptions = faiss::gpu::INDICES_CPU;
+    cfg16.flatConfig.useFloat16 = co.useFloat16CoarseQuantizer;
+    cfg16.flatConfig.storeTransposed = co.storeTransposed;
+    cfg16.useFloat16LookupTables = co.useFloat16;
+    cfg16.usePrecomputedTables = co.usePrecomputed;
+    EXPECT(co.usePrecomputed && co.indicesOptions == faiss::gpu::INDICES_64_BIT && co.reserveVecs == 0);
+    faiss::gpu::GpuIndexIVFPQ drv(&resources, d, ncentroids, 16, 8, /*nedge*/ 8, /*nLambda*/ 32, faiss::METRIC_L2, cfg16);
+    faiss::gpu::GpuIndexIVFPQConfig cfg32;
+    cfg32.usePrecomputedTables = true;
+    faiss::gpu::GpuIndexIVFPQ base(&resources, d, ncentroids, 16, 8, 8, 32, faiss::METRIC_L2, cfg32);
+    std::vector<faiss::Index::idx_t> n16((size_t)k * nq), n32((size_t)k * nq);
+    std::vector<float> d16((size_t)k * nq), d32((size_t)k * nq);
+    faiss::gpu::GpuIndexIVFPQ* both[2] = {&drv, &base};
+    for (auto* ix : both) {
+      ix->train(nt, trainvecs.data());
+      ix->add(nb, database.data());
+      ix->setNumProbes(5);
+      ix->w1_ = 40;
+    }
+    drv.search(nq, queries.data(), k, d16.data(), n16.data());
+    base.search(nq, queries.data(), k, d32.data(), n32.data());
+    EXPECT(drv.getFloat16LookupTables() && !base.getFloat16LookupTables());
+    EXPECT(n16 == n32 && d16 == d32);
+    // the same options on the plain IVFPQ copy-constructor (GpuAutoTune.cpp's cloner fills them in alike)
+    faiss::gpu::GpuIndexIVFPQ copy16(&resources, &index, cfg16);
+    copy16.setNumProbes(5);
+    copy16.search(nq, queries.data(), k, d16.data(), n16.data());
+    EXPECT(n16 == nns && d16 == dis);
+    faiss::gpu::GpuMultipleClonerOptions mco;
+    EXPECT(!mco.shard && mco.usePrecomputed);
+    printf("part 2e: reference driver configuration (useFloat16LookupTables, INDICES_CPU) accepted, answers equal fp32\n");
   }
 
   // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of

@@ -51,3 +51,19 @@ def test_gpu_shell_builds_against_reference_headers():
     p = subprocess.run(["./link_against_reference"], cwd=CPP, env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "reference CPU index: ntotal=2000 use_precomputed_table=1" in p.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_shell_with_reference_library_on_gpu():
+    """INTEGRATION.md §A executed: the binary prebuilt in the build container (reference headers +
+    libfaiss_ref.so + this library) copies a REFERENCE-class IndexIVFPQ to the MI355X and both answer
+    the same queries identically."""
+    exe = os.path.join(CPP, "link_against_reference")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
+        pytest.skip("link_against_reference was not prebuilt (needs the reference tree at build time)")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "oracle/_ref/mkl") + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, "gpu"], cwd=CPP, env=env, capture_output=True, text=True, timeout=600)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "distances bit-equal, labels equal" in p.stdout and "copyTo -> reference cpu: equal" in p.stdout

@@ -1,0 +1,227 @@
+"""GPU: the BASELINE.json configurations at THEIR OWN geometry, each under the oracle.
+
+* configs[2] (tests/sift1b_imi_pq.cpp:225-236): inverted multi-index 2 x 14 bits = 2^28 lists,
+  16 384-column half tables (coarse_select_tiled_kernel + tile minima inside imi_page), table
+  type 2 (IndexIVFPQ.cpp:430-457, :645-686), 2 GB list_off / list_len arrays, nprobe 64, k 10.
+* configs[3] (deep1b shape): d = 96 (dsub = 6), 2^17 lists, nprobe 128 -- covered by
+  test_gpu_fullsize.py::test_many_lists_deep1b_shape; here only its IMI 2 x 14 variant at d = 96.
+* configs[4] / SURVEY C5 (gpu/test/deep1b16_query.cpp:206-208,326,337-340): VLQ with
+  nlist = 65 536, nedge = 64 (4.19 M lines), nLambda = 256, M = 16 x 8 bit, nprobe = 64,
+  w1 = 1024, k = 128.
+
+The database is reduced (a few 10^5 vectors: the oracle has to finish in seconds) and laid out
+so that the probed cells / lines hold codes; every structure that depends on the GEOMETRY -- table
+widths, select kernels, key widths, offset arrays, line-id arithmetic -- runs at full size.
+The device encodes the database (encode parity itself is checked on a sample against the oracle);
+both sides then search the same lists and must agree bit for bit."""
+import numpy as np
+import pytest
+
+import vector_line_quantization_amd as vlq
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------------------------
+# IMI 2 x 14
+# ----------------------------------------------------------------------------------------------
+def _imi_world(nbits, d, nq=64, per=3000, sigma=0.4, seed=14):
+    from oracle.pyoracle import OracleIndex
+    M = 16
+    kc, dc = 1 << nbits, d // 2
+    nlist = kc * kc
+    rng = np.random.default_rng(seed)
+    imi = rng.random((2, kc, dc), dtype=np.float32)
+    imi[0, 100:104] = imi[0, 7]          # runs of equal sub-centroids: equal table entries, equal sums
+    imi[1, 9000 % kc:9000 % kc + 2] = imi[1, 3]
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.3).astype(np.float32)
+    a, b = rng.integers(0, kc, nq), rng.integers(0, kc, nq)
+    a[:3], b[:3] = 7, 3                  # queries sitting on the duplicated sub-centroids
+    xq = (np.concatenate([imi[0, a], imi[1, b]], 1) + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    xq[0] = np.concatenate([imi[0, 7], imi[1, 3]])      # exactly on a cell corner
+    xb = (np.repeat(xq, per, 0) + sigma * rng.standard_normal((nq * per, d))).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    assign, codes = g.encode(xb)
+    assert assign.min() >= 0 and assign.max() < nlist
+    order = np.argsort(assign, kind="stable")
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(np.bincount(assign, minlength=nlist), out=off[1:])
+    ids = (np.arange(xb.shape[0], dtype=np.int64) * 7 + 11)[order]
+    codes_l = np.ascontiguousarray(codes[order])
+    g.set_lists(codes_l, ids, off)
+    ox = OracleIndex(d, nlist, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits,
+                     codes=codes_l, ids=ids, list_offsets=off)
+    return g, ox, xq, xb, assign, codes
+
+
+@pytest.fixture(scope="module")
+def imi14():
+    return _imi_world(14, 128)
+
+
+def test_imi_2x14_encode_sample_matches_oracle(imi14):
+    g, ox, xq, xb, assign, codes = imi14
+    pick = np.arange(0, xb.shape[0], xb.shape[0] // 1500)[:1500]
+    ao, co = ox.encode(xb[pick], canonical=True)
+    assert np.array_equal(assign[pick], ao)
+    assert np.array_equal(codes[pick], co)
+
+
+def test_imi_2x14_coarse_bit_exact(imi14):
+    """Both 16 384-column half tables (MFMA distance kernel with tile minima + tiled select) and the
+    MinSumK walk (IndexPQ.cpp:690-857) at nprobe = 64: keys and the path-dependent sums, bit for bit."""
+    g, ox, xq, _, _, _ = imi14
+    cd, keys = g.coarse_search(xq, 64)
+    cdo, keyso = ox.coarse_search(xq, 64, canonical=True)
+    assert np.array_equal(keys, keyso)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert keys.max() >= 1 << 27            # keys really use the upper sub-index bits
+
+
+def test_imi_2x14_full_search_bit_exact(imi14):
+    """sift1b_imi_pq.cpp's search call (nprobe 64, k 10) at 2^28 lists: coarse_dis, keys, D, I."""
+    g, ox, xq, xb, _, _ = imi14
+    g.stats(reset=True)
+    D, I = g.search(xq, 64, 10)
+    Do, Io, keyso, cdo = ox.search(xq, 64, 10, canonical=True, return_coarse=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    _nq, ncode = g.stats(reset=True)
+    assert ncode == ox.last_ncode and ncode > 64 * 200      # the probed cells do hold codes
+    # larger selections and the preassigned seam on the same index
+    D2, I2 = g.search(xq, 64, 100)
+    Do2, Io2 = ox.search(xq, 64, 100, canonical=True)
+    assert np.array_equal(bits(D2), bits(Do2)) and np.array_equal(I2, Io2)
+    Dp, Ip = g.search_preassigned(xq, keyso, cdo, 10)
+    assert np.array_equal(bits(Dp), bits(Do)) and np.array_equal(Ip, Io)
+
+
+def test_imi_2x14_batch_of_paged_size(imi14):
+    """10 000 queries = the driver's batch: one coarse page (2 x 655 MB tables), short-list scan,
+    spatial query order with 2^28 lists binned by the high key bits -- a sample against the oracle."""
+    g, ox, xq, xb, _, _ = imi14
+    rng = np.random.default_rng(5)
+    big = (xb[rng.integers(0, xb.shape[0], 10000)] + 0.01 * rng.standard_normal((10000, xb.shape[1]))).astype(np.float32)
+    D, I = g.search(big, 64, 10)
+    pick = rng.integers(0, 10000, 48)
+    Do, Io = ox.search(big[pick], 64, 10, canonical=True)
+    assert np.array_equal(bits(D[pick]), bits(Do)) and np.array_equal(I[pick], Io)
+
+
+@pytest.mark.parametrize("nbits,dc,nprobe", [(13, 64, 64), (14, 64, 64), (14, 48, 128), (14, 8, 64), (13, 64, 1),
+                                             (14, 64, 1000)])
+def test_imi_half_table_select_with_tie_runs(nbits, dc, nprobe):
+    """The half-table selects alone at 8192 / 16 384 columns, with long runs of EXACTLY equal
+    entries inside one 64-column tile, across tiles and across the tile-minimum cut: the
+    multi-index coarse search must return the oracle's keys and sums bit for bit
+    (IndexPQ.cpp:804-857; nprobe = 1 takes the arg-min epilogue, dc = 8 the SSE table path)."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(nbits * 100 + dc + nprobe)
+    kc, d, M = 1 << nbits, 2 * dc, 4
+    imi = rng.random((2, kc, dc), dtype=np.float32)
+    imi[0, 10:45] = imi[0, 3]                       # 36 equal columns inside tile 0
+    imi[0, 60:70] = imi[0, 3]                       # the run continues across the tile edge
+    imi[0, kc - 5:] = imi[0, 3]                     # ... and at the far end of the row
+    imi[1, 64 * 17:64 * 17 + 64] = imi[1, 64 * 17]  # one whole tile of equal columns
+    imi[1, 5000:5003] = imi[1, 64 * 17]
+    pq = rng.random((M, 256, d // M), dtype=np.float32)
+    xq = rng.random((33, d), dtype=np.float32)
+    xq[:6, :dc] = imi[0, 3] + 0.001 * rng.standard_normal((6, dc)).astype(np.float32)   # the runs are the nearest entries
+    xq[:6, dc:] = imi[1, 64 * 17]
+    g = vlq.GpuIVFPQ(d, kc * kc, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, kc * kc, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits)
+    cd, keys = g.coarse_search(xq, nprobe)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(keys, keyso)
+    assert np.array_equal(bits(cd), bits(cdo))
+
+
+def test_imi_2x14_d96_deep1b_imi_shape():
+    """deep1b_imi_pq.cpp's shape: d = 96 (48-dim halves, dsub = 6), IMI 2 x 14, nprobe 128."""
+    g, ox, xq, xb, _, _ = _imi_world(14, 96, nq=24, per=2000, sigma=0.45, seed=96)
+    D, I = g.search(xq, 128, 100)
+    Do, Io = ox.search(xq, 128, 100, canonical=True)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
+# ----------------------------------------------------------------------------------------------
+# VLQ at the reference driver's geometry (C5)
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vlq_c5():
+    from oracle.pyoracle import OracleVLQ
+    d, nlist, nedge, M, nlambda = 96, 65536, 64, 16, 256
+    rng = np.random.default_rng(65)
+    coarse = rng.random((nlist, d), dtype=np.float32)
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.25).astype(np.float32)
+    lam = np.linspace(-0.25, 1.25, nlambda).astype(np.float32)
+    g = vlq.GpuVLQ(d, nlist, M, 8, nedge, nlambda)
+    g.set_coarse_centroids(coarse)
+    ei, ed = g.build_graph()                 # 65 536 x 64 graph on the device (parity: test_gpu_vlq.py)
+    g.set_lambda_codebook(lam)
+    g.set_pq_centroids(pq)
+    # database: 40 % spread over all centroids, 60 % crowded onto 300 of them (lines longer than the
+    # 1024-code cap, many empty lines); queries = perturbed members of the crowded part
+    nb = 400000
+    hot = rng.integers(0, nlist, 300)
+    pick = np.where(rng.random(nb) < 0.6, hot[rng.integers(0, 300, nb)], rng.integers(0, nlist, nb))
+    nbr = ei[pick, rng.integers(0, 8, nb)]    # towards one of the 8 nearest neighbours
+    t = rng.random((nb, 1), dtype=np.float32) * 1.2 - 0.1
+    xb = ((1 - t) * coarse[pick] + t * coarse[nbr] + 0.05 * rng.standard_normal((nb, d))).astype(np.float32)
+    line, lb, codes = g.encode(xb)
+    nl = nlist * nedge
+    order = np.argsort(line, kind="stable")
+    off = np.zeros(nl + 1, np.int64)
+    np.cumsum(np.bincount(line, minlength=nl), out=off[1:])
+    ids = (np.arange(nb, dtype=np.int64) * 3 + 1)[order]
+    codes_l, lam_l = np.ascontiguousarray(codes[order]), np.ascontiguousarray(lb[order])
+    g.set_lists(codes_l, lam_l, ids, off)
+    v = OracleVLQ(d, nlist, M, 8, nedge, nlambda, coarse, pq_centroids=pq, edge_info=ei, edge_dist=ed, lambda_info=lam)
+    v.codes, v.lambdas, v.ids, v.line_off = codes_l, lam_l, ids, off
+    nq = 24
+    src = np.flatnonzero(np.isin(pick, hot))[:nq]
+    xq = (xb[src] + 0.02 * rng.standard_normal((nq, d))).astype(np.float32)
+    return g, v, xq, xb, (line, lb, codes), off
+
+
+def test_vlq_c5_encode_sample_matches_oracle(vlq_c5):
+    g, v, xq, xb, (line, lb, codes), _ = vlq_c5
+    pick = np.arange(0, xb.shape[0], xb.shape[0] // 600)[:600]
+    lo, lbo, co = v.encode(xb[pick])
+    assert np.array_equal(line[pick], lo) and np.array_equal(lb[pick], lbo) and np.array_equal(codes[pick], co)
+
+
+def test_vlq_c5_search_bit_exact(vlq_c5):
+    """deep1b16_query.cpp's call: nprobe 64, w1 1024, k 128 -- the 4096 candidate lines per query,
+    the 1024 kept ones in the reference's emitted order, distances and ids, bit for bit."""
+    g, v, xq, _, _, off = vlq_c5
+    assert np.diff(off).max() > 1024        # the 1024-code cap is exercised
+    g.stats(reset=True)
+    D, I, lines = g.search(xq, 64, 1024, 128, return_lines=True)
+    Do, Io, lo = v.search(xq, 64, 1024, 128, return_lines=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    assert g.stats(reset=True) == v.last_ncode > xq.shape[0] * 2000
+
+
+def test_vlq_c5_recall_against_brute_force(vlq_c5):
+    """Oracle-independent: the VLQ search must find the true nearest database vector (exact L2 on
+    the raw vectors) about as often as 17-byte codes allow -- a wrong formula, line geometry or id
+    mapping would send this to chance level."""
+    g, v, xq, xb, _, _ = vlq_c5
+    D, I = g.search(xq, 64, 1024, 128)
+    order_ids = v.ids
+    pos_of = np.empty(xb.shape[0] * 3 + 2, np.int64)
+    pos_of[order_ids] = np.arange(order_ids.shape[0])
+    hit = 0
+    for qi in range(xq.shape[0]):
+        d2 = ((xb - xq[qi]) ** 2).sum(1)
+        gt = int(np.argmin(d2)) * 3 + 1
+        hit += gt in I[qi]
+    assert hit >= 0.8 * xq.shape[0], hit

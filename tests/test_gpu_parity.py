@@ -316,9 +316,35 @@ def test_empty_and_error_paths():
     with pytest.raises(vlq.VlqError):
         g.search(case.xq, 4, 2000)
     bad = np.full((case.nq, 2), case.nlist + 3, np.int64)
-    g.search_preassigned(case.xq, bad, np.zeros((case.nq, 2), np.float32), 3)
-    with pytest.raises(vlq.VlqError):                    # reference: "Invalid key" + throw
+    with pytest.raises(vlq.VlqError):                    # reference: "Invalid key" + throw (IndexIVFPQ.cpp:1008-1011)
+        g.search_preassigned(case.xq, bad, np.zeros((case.nq, 2), np.float32), 3)
+    g.stats()                                            # ... reported once, then cleared
+    # device outputs: the call stays asynchronous, the error surfaces at the next stats()
+    import torch
+    Dd = torch.empty((case.nq, 3), dtype=torch.float32, device="cuda")
+    Id = torch.empty((case.nq, 3), dtype=torch.int64, device="cuda")
+    g.search_preassigned(torch.from_numpy(case.xq).cuda(), torch.from_numpy(bad).cuda(),
+                         torch.zeros((case.nq, 2), dtype=torch.float32, device="cuda"), 3, D=Dd, I=Id)
+    with pytest.raises(vlq.VlqError):
         g.stats()
+    with pytest.raises(ValueError):                      # outputs are written in place: no silent temporaries
+        g.search(case.xq, 4, 3, D=np.empty((case.nq, 6), np.float32)[:, ::2], I=np.empty((case.nq, 3), np.int64))
+
+
+def test_negative_user_ids_survive_every_path():
+    """add_with_ids accepts any int64 (IndexIVFPQ.cpp:236-248): negative ids must come back from the
+    single-workgroup scan, the split scan + merge (small batches) and vlq_merge_topk alike."""
+    case = Case("c1_small")
+    g = gpu_index(case, with_lists=False)
+    neg = -(np.arange(case.xb.shape[0], dtype=np.int64) + 5)
+    g.add(case.xb, neg)
+    ox = case.oracle_index(with_lists=False)
+    ox.add(case.xb, neg, canonical=True)
+    for nq in (2, case.nq):                              # 2 queries: probes split over workgroups + merge
+        D, I = g.search(case.xq[:nq], case.nprobe, case.k)
+        Do, Io = ox.search(case.xq[:nq], case.nprobe, case.k, canonical=True)
+        assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+        assert (I[D < np.finfo(np.float32).max] < 0).all()
 
 
 def test_device_resident_buffers():
@@ -348,6 +374,7 @@ def test_merge_topk(k, nparts):
     I = rng.integers(0, 10 ** 9, (nparts, nq, k)).astype(np.int64)
     D[1, :, k // 2:] = np.finfo(np.float32).max
     I[1, :, k // 2:] = -1
+    I[0, :, 0] = -7 - np.arange(nq)             # negative ids are data, not padding
     Dd, Id = torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda()
     Do = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     Io = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -358,7 +385,7 @@ def test_merge_topk(k, nparts):
     torch.cuda.synchronize()
     allD = np.concatenate(list(D), axis=1)
     allI = np.concatenate(list(I), axis=1)
-    order = np.argsort(np.where(allI < 0, np.inf, allD), axis=1, kind="stable")[:, :k]
+    order = np.argsort(np.where(allD == np.finfo(np.float32).max, np.inf, allD), axis=1, kind="stable")[:, :k]
     assert np.array_equal(Do.cpu().numpy(), np.take_along_axis(allD, order, 1))
     assert np.array_equal(Io.cpu().numpy(), np.take_along_axis(allI, order, 1))
 

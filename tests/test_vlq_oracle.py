@@ -98,3 +98,135 @@ def test_search_with_all_lines_is_exhaustive_over_the_scanned_codes():
         allv = np.array([((q - decode(v, p)) ** 2).sum() - (q ** 2).sum() for p in range(800)])
         best = np.sort(allv)[:5]
         assert np.allclose(D[qi], best, rtol=1e-3, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# Oracle-INDEPENDENT restatements: plain numpy transliterations of the CUDA kernels' text, written
+# without looking at oracle/vlq_oracle.cpp's code paths (the oracle and the HIP kernels were written
+# together; these are the second opinion).  float32 arithmetic, numpy's own summation order for the
+# distances (the reference tree-reduces across a block, gpu/GpuIndexFlat.cu:476-491: unpinned), so
+# choices may differ on near-ties only.
+# ---------------------------------------------------------------------------------------------
+def np_get1bin(x, A, coarse, edge_info, edge_dist):
+    """get1BinKernel_nms, gpu/GpuIndexFlat.cu:433-557, for one vector x with nearest centroid A:
+    dist[a] = |x - c_s|^2 for the edges' far ends (:470-492), dist[d_edge] = |x - c_A|^2 (:496-513);
+    lambda = project(a, b, c), q2 = dist2(a, b, c, lambda) (:516-527; utils/triangle.cuh:54-87);
+    sort by q2 (:530); first edge in that order with 0 <= lambda <= 1, else the overall best (:532-546)."""
+    f = np.float32
+    nedge = edge_info.shape[1]
+    a = np.array([((x - coarse[edge_info[A, e]]) ** 2).sum(dtype=f) for e in range(nedge)], f)
+    b = ((x - coarse[A]) ** 2).sum(dtype=f)
+    c = edge_dist[A].astype(f)
+    lam = f(-0.5) * (a - b - c) / c
+    q2 = b + lam * lam * c + lam * (a - b - c)
+    order = np.argsort(q2, kind="stable")
+    edge, la = order[0], lam[order[0]]
+    for i in order:
+        if 0 <= lam[i] <= 1:
+            edge, la = i, lam[i]
+            break
+    return A * nedge + edge, la, q2
+
+
+def np_assign_lambda(val, lambda_info):
+    """assignLambdaKernel, gpu/GpuIndexFlat.cu:559-602: nearest codebook scalar by (val - l)^2."""
+    t = np.float32(val) - lambda_info.astype(np.float32)
+    return int(np.argmin(t * t))
+
+
+def test_assignment_matches_numpy_transliteration_of_the_cuda_kernels():
+    v, xb, _ = make_vlq(seed=21, d=48, nlist=40, nedge=7, nlambda=32, nb=200)
+    x = xb[:400] if xb.shape[0] >= 400 else xb
+    line, lam = v.assign(x)
+    near = v.nearest(x)
+    lb = v.quantize_lambda(lam)
+    same = 0
+    for i in range(x.shape[0]):
+        ln, la, q2 = np_get1bin(x[i], int(near[i]), v.coarse, v.edge_info, v.edge_dist)
+        if ln == line[i]:
+            same += 1
+            assert abs(la - lam[i]) <= 2e-4 * max(1.0, abs(la))
+        else:   # a different edge is only acceptable when the two candidates are equal to rounding
+            e_or, e_np = line[i] % v.nedge, ln % v.nedge
+            assert abs(q2[e_or] - q2[e_np]) <= 1e-4 * max(1.0, abs(q2[e_np]))
+        assert np_assign_lambda(lam[i], v.lambda_info) == lb[i] or \
+            abs(abs(lam[i] - v.lambda_info[lb[i]]) - np.abs(lam[i] - v.lambda_info).min()) < 1e-6
+    assert same >= 0.98 * x.shape[0]
+
+
+def test_scan_formula_matches_numpy_transliteration():
+    """pqScanPrecomputedMultiPassGraph (PQScanMultiPassPrecomputed.cu:744-811) and
+    sumAlongRowsWithOrder2 (BroadcastSum.cu:498-553) restated in numpy float32 from the CUDA text:
+    line keys, kept lines in emitted order, per-code distances -- against the oracle's search."""
+    f = np.float32
+    v, xb, xq = make_vlq(seed=8, d=32, nlist=30, M=8, nbits=6, nedge=5, nlambda=16, nb=1500)
+    nprobe, w1, k = 6, 12, 8
+    D, I, lines = v.search(xq[:12], nprobe, w1, k, return_lines=True)
+    t2 = v.term2.reshape(v.nlist, v.M, v.ksub)
+    full = 0
+    for qi in range(12):
+        q = xq[qi]
+        # coarse "distances" without |q|^2 (Distance.cu:286-291)
+        vv = (v.coarse * v.coarse).sum(1, dtype=f) - f(2) * (v.coarse @ q).astype(f)
+        probes = np.argsort(vv, kind="stable")[:nprobe]
+        keys, cand = [], []
+        for r, c in enumerate(probes):
+            for e in range(v.nedge):
+                s = v.edge_info[c, e]
+                vd = f(vv[s] - vv[c])
+                t = f(vd - v.edge_dist[c, e])
+                keys.append(vv[c] if t > 0 else f(vv[c] - f(0.25) * t * t / v.edge_dist[c, e]))
+                cand.append((c, e, s, vd))
+        order = np.argsort(np.array(keys, f), kind="stable")[:w1]
+        kept = [cand[i] for i in order]
+        got = [int(c) * v.nedge + e for c, e, _, _ in kept]
+        # coarse sums differ in rounding between numpy's matmul and the oracle's fmaf chain: compare the
+        # line SETS and, when the emitted order is identical, the full distance computation
+        assert len(set(got) & set(int(x) for x in lines[qi])) >= w1 - 2
+        if got != [int(x) for x in lines[qi]]:
+            continue
+        ip = np.stack([(v.pq_centroids[m] @ q[m * v.dsub:(m + 1) * v.dsub]).astype(f) for m in range(v.M)])
+        t3 = f(-2) * ip
+        res = []
+        for (c, e, s, vd) in kept:
+            line = int(c) * v.nedge + e
+            o0 = v.line_off[line]
+            n = min(v.line_off[line + 1] - o0, 1024)
+            t23, t4 = t2[c] + t3, t2[s] - t2[c]
+            for j in range(n):
+                la = v.lambda_info[v.lambdas[o0 + j]]
+                dist = f(f(vv[c] + la * vd) + f(la * la - la) * v.edge_dist[c, e])
+                tmp = f(0)
+                for m in range(v.M):
+                    dist = f(dist + t23[m, v.codes[o0 + j, m]])
+                    tmp = f(tmp + t4[m, v.codes[o0 + j, m]])
+                res.append((f(dist + la * tmp), v.ids[o0 + j]))
+        res.sort(key=lambda t: t[0])
+        ref = np.array([r[0] for r in res[:k]], f)
+        assert np.allclose(D[qi][:len(ref)], ref, rtol=2e-5, atol=2e-5), (qi, D[qi], ref)
+        full += 1
+    assert full >= 8, full
+
+
+def test_encoding_reduces_the_reconstruction_error():
+    """Encode / decode bound: the stored point (anchor on the line + PQ residual) is closer to the
+    vector than its nearest centroid alone and than the bare anchor -- on average, for data that has
+    residual structure (what the two quantization stages are for)."""
+    v, xb, _ = make_vlq(seed=4, nb=1200)
+    e_cent = e_anchor = e_full = 0.0
+    near = v.nearest(xb)
+    order = {int(i): p for p, i in enumerate(v.ids)}
+    for i in range(0, xb.shape[0], 3):
+        x = xb[i].astype(np.float64)
+        pos = order[i]
+        line = np.searchsorted(v.line_off, pos, side="right") - 1
+        c, e = line // v.nedge, line % v.nedge
+        assert c == near[i]
+        s = v.edge_info[c, e]
+        l = float(v.lambda_info[v.lambdas[pos]])
+        anchor = (1 - l) * v.coarse[c].astype(np.float64) + l * v.coarse[s].astype(np.float64)
+        e_cent += ((x - v.coarse[c]) ** 2).sum()
+        e_anchor += ((x - anchor) ** 2).sum()
+        e_full += ((x - decode(v, pos)) ** 2).sum()
+    assert e_anchor <= e_cent * 1.0001
+    assert e_full < e_anchor

@@ -347,10 +347,14 @@ int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t by
     return VLQ_OK;
 }
 
+// An out-of-range probe key aborts the reference's search (IndexIVFPQ.cpp:1008-1011).  The scan
+// kernels raise a device flag; call this after the stream has been synchronised (host outputs).
 int read_bad_key(vlq_ivfpq_t h) {
-    // only meaningful after a synchronisation; checked lazily in vlq_ivfpq_stats
-    (void)h;
-    return VLQ_OK;
+    int bad = 0;
+    HIP_TRY(hipMemcpy(&bad, reinterpret_cast<const char*>(h->stats.p) + 8, sizeof(int), hipMemcpyDeviceToHost));
+    if (!bad) return VLQ_OK;
+    HIP_TRY(hipMemset(reinterpret_cast<char*>(h->stats.p) + 8, 0, 8));
+    return fail(VLQ_ERR_INVALID, "a probe key >= nlist was passed to search_preassigned (IndexIVFPQ.cpp:1008-1011)");
 }
 
 }  // namespace
@@ -686,7 +690,11 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
     TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
     TRY(scan_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k,
                  (float*)Dd, (int64_t*)Id, store_pairs));
-    return finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8);
+    TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
+    // host outputs: the call has synchronised, so an invalid key is reported here and now; device
+    // outputs: the call stays asynchronous and the flag surfaces at the next vlq_ivfpq_stats()
+    if (copyD || copyI) TRY(read_bad_key(h));
+    return VLQ_OK;
 }
 
 int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k, float* D,

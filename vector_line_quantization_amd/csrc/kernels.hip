@@ -1047,8 +1047,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         float v = 0.f;
         if (valid) {
             const int64_t src = ((int64_t)(i / k) * nq + q) * k + (i % k);
+            // padding entries are (FLT_MAX, -1): the strict admission below never takes FLT_MAX, and a
+            // real result is always < FLT_MAX (Heap.h:76-78), so padding is recognised by its distance --
+            // NOT by id < 0: callers may store negative ids (add_with_ids)
             v = Dp[src];
-            valid = Ip[src] >= 0;          // padding entries (-1 / FLT_MAX) never win
         }
         sel.offer(v, (uint32_t)i, valid);
     }

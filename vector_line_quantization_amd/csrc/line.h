@@ -12,7 +12,7 @@ void launch_lambda_quantize(const float* lambdaf, int64_t n, const float* lambda
 void launch_line_residuals(const float* x, int64_t n, int d, const float* coarse, const int32_t* edge_info,
                            int nedge, const int32_t* line_id, const uint8_t* lambda,
                            const float* lambda_info, float* res, hipStream_t s);
-// one selected, non-empty line as the 16-byte scan kernel reads it (32 bytes = two 16-byte loads)
+// one selected, non-empty line as the 16-byte scan kernel reads it (48 bytes = three 16-byte loads)
 struct LineMeta {
     int64_t off;      // first code of the line
     int32_t len;      // codes scanned (capped at max_line_codes)
@@ -21,7 +21,12 @@ struct LineMeta {
     float c2;         // |s - c|^2
     float b2;         // coarse value of the anchor c
     float g;          // v[s] - v[c]
+    uint32_t pos0;    // scan position of the line's first code: lines in the order the line select emits
+                      // them (ascending key, BroadcastSum.cu:538-553), codes in list order
+    int32_t rank;     // index of the line among the query's non-empty kept lines in that order
+    int32_t pad0, pad1;
 };
+static_assert(sizeof(LineMeta) == 48, "LineMeta is read as three 16-byte words");
 
 // sel_meta / sel_cnt (optional): compact LineMeta records [nq][w1] + their count per query
 void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,

@@ -172,25 +172,18 @@ __global__ __launch_bounds__(256) void line_select_kernel(
         sel.offer(key, (uint32_t)i, valid);
     }
     sel.flush();
-    // the w1 winners, re-sorted by candidate index (probe rank, edge): lines sharing an anchor
-    // centroid become neighbours, so the scan builds the anchor's table once per group
-    WaveSelect<KPL> ord;
-    ord.init(w1, queue[wave], lane);
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const u64 k64 = sel.best[r];
-        const bool win = k64 != kMaxKey && r * 64 + lane < w1;
-        ord.offer_key((u64)(uint32_t)k64, win);
-    }
-    ord.flush();
+    // (1) the w1 winners in ascending key order -- the order sumAlongRowsWithOrder2 emits them in
+    // (BroadcastSum.cu:538-553) and therefore the order of the scan's output array: scan positions,
+    // the tie rule of the final top-k, follow THIS order
+    uint32_t len_r[KPL];
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const int w = r * 64 + lane;
-        if (w >= w1) continue;
-        const u64 k64 = ord.best[r];
+        const u64 k64 = sel.best[r];
         int32_t line = -1;
         float b2 = 0.f, g = 0.f;
-        if (k64 != kMaxKey) {
+        uint32_t len = 0;
+        if (w < w1 && k64 != kMaxKey) {
             const int i = (int)(uint32_t)k64;
             const int64_t c = kq[i / nedge];
             const int e = i % nedge;
@@ -198,41 +191,72 @@ __global__ __launch_bounds__(256) void line_select_kernel(
             line = (int32_t)(c * nedge + e);
             b2 = row[c];
             g = __fsub_rn(row[s], b2);
+            if (sel_meta) {
+                int64_t l64 = line_len ? line_len[line] : line_off[line + 1] - line_off[line];
+                if (l64 > max_line_codes) l64 = max_line_codes;
+                len = (uint32_t)l64;
+            }
         }
-        sel_line[q * w1 + w] = line;
-        sel_b2[q * w1 + w] = b2;
-        sel_g[q * w1 + w] = g;
+        if (w < w1) {
+            sel_line[q * w1 + w] = line;
+            sel_b2[q * w1 + w] = b2;
+            sel_g[q * w1 + w] = g;
+        }
+        len_r[r] = len;
     }
     if (!sel_meta) return;
-    // compact per-line records for the 16-byte scan: non-empty lines only, same order
-    int nkept = 0;
+    // (2) compact records for the 16-byte scan: the non-empty lines, each with its scan position and
+    // its rank in the emitted order, but stored in candidate order (probe rank, edge) so that lines
+    // sharing an anchor centroid are neighbours and the scan builds the anchor's table once per group.
+    // Sort key = candidate index << 40 | rank << 30 | position (w1, codes per line <= 1024; the host
+    // checks nprobe * nedge < 2^24).
+    WaveSelect<KPL> ord;
+    ord.init(w1, queue[wave], lane);
+    uint32_t run_pos = 0, run_cnt = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const bool keep = len_r[r] > 0;
+        const u64 mask = __ballot(keep);
+        const uint32_t rank = run_cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t inc = len_r[r];
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = __shfl_up(inc, sft, 64);
+            if (lane >= sft) inc += o;
+        }
+        const uint32_t pos0 = run_pos + inc - len_r[r];
+        run_pos += __shfl(inc, 63, 64);
+        run_cnt += (uint32_t)__popcll(mask);
+        const u64 i = (uint32_t)sel.best[r];
+        ord.offer_key((i << 40) | ((u64)rank << 30) | pos0, keep);
+    }
+    ord.flush();
+    // only non-empty lines were offered: sorted elements 0 .. run_cnt-1 are the records
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const int w = r * 64 + lane;
         const u64 k64 = ord.best[r];
+        if (w >= (int)run_cnt || k64 == kMaxKey) continue;
+        const int i = (int)(k64 >> 40);
+        const int64_t c = kq[i / nedge];
+        const int e = i % nedge;
+        const int64_t line = c * nedge + e;
         LineMeta m;
-        m.len = 0;
-        if (w < w1 && k64 != kMaxKey) {
-            const int i = (int)(uint32_t)k64;
-            const int64_t c = kq[i / nedge];
-            const int e = i % nedge;
-            const int64_t line = c * nedge + e;
-            m.off = line_off[line];
-            int64_t len = line_len ? line_len[line] : line_off[line + 1] - m.off;
-            if (len > max_line_codes) len = max_line_codes;
-            m.len = (int32_t)len;
-            m.line = (int32_t)line;
-            m.s = edge_info[line];
-            m.c2 = edge_dist[line];
-            m.b2 = row[c];
-            m.g = __fsub_rn(row[m.s], m.b2);
-        }
-        const bool keep = m.len > 0;
-        const u64 mask = __ballot(keep);
-        if (keep) sel_meta[q * w1 + nkept + __popcll(mask & ((1ull << lane) - 1ull))] = m;
-        nkept += __popcll(mask);
+        m.off = line_off[line];
+        int64_t len = line_len ? line_len[line] : line_off[line + 1] - m.off;
+        if (len > max_line_codes) len = max_line_codes;
+        m.len = (int32_t)len;
+        m.line = (int32_t)line;
+        m.s = edge_info[line];
+        m.c2 = edge_dist[line];
+        m.b2 = row[c];
+        m.g = __fsub_rn(row[m.s], m.b2);
+        m.pos0 = (uint32_t)k64 & ((1u << 30) - 1u);
+        m.rank = (int32_t)((k64 >> 30) & 1023u);
+        m.pad0 = m.pad1 = 0;
+        sel_meta[q * w1 + w] = m;
     }
-    if (lane == 0) sel_cnt[q] = nkept;
+    if (lane == 0) sel_cnt[q] = (int32_t)run_cnt;
 }
 
 void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe,
@@ -332,7 +356,8 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
     float* t4 = t23 + E;                                             // [E] at LDS byte 16384
     float* lamtab = t4 + E;                                          // [256]
     u64* queue = reinterpret_cast<u64*>(smraw + queue_off);          // [4][64]
-    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1] scan position of the rank-th line
+    uint16_t* wmap = reinterpret_cast<uint16_t*>(cum + a.w1 + 1);    // [w1] rank -> record index
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
     asm volatile("" : "+v"(two));
     const int64_t q = blockIdx.x;
     const int cnt = a.sel_cnt[q];
-    const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);
+    const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);   // 3 x 16 bytes per record
 
     float4 m2q[NI];                       // -2 <q_m, cent_mj>, entries 4*(i*256+t) .. +3
     {
@@ -369,15 +394,15 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
         c0 = reinterpret_cast<const uint4*>(a.codes)[off + j];
         l0 = a.lambdas[off + j];
     };
-    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, mb0 = ma0, mb1 = ma0;
+    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, ma2 = ma0, mb0 = ma0, mb1 = ma0, mb2 = ma0;
     if (cnt > 0) {
-        ma0 = mq[0]; ma1 = mq[1];
+        ma0 = mq[0]; ma1 = mq[1]; ma2 = mq[2];
         const int w1c = min(1, cnt - 1);
-        mb0 = mq[2 * w1c]; mb1 = mq[2 * w1c + 1];
+        mb0 = mq[3 * w1c]; mb1 = mq[3 * w1c + 1]; mb2 = mq[3 * w1c + 2];
         prefetch(ma0, ma1);
     }
     int cprev = -1;
-    uint32_t pos0 = 0;
+    uint32_t total = 0;
     for (int w = 0; w < cnt; w++) {
         const int64_t off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane(ma0.y) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane(ma0.x));
@@ -386,8 +411,12 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
         const float c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.y));
         const float b2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.z));
         const float g = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.w));
+        // scan position of the line's first code and the line's rank, both in the emitted (ascending
+        // key) order of the line select; the records themselves come grouped by anchor
+        const uint32_t pos0 = __builtin_amdgcn_readfirstlane(ma2.x);
+        const int rank = __builtin_amdgcn_readfirstlane(ma2.y);
         const int c = line / a.nedge;
-        if (t == 0) cum[w] = pos0;
+        if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
         __syncthreads();                         // previous line fully scanned
         if (c != cprev) {                        // new anchor: its row into registers, T23 into LDS
             const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)c * E);
@@ -411,11 +440,11 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
         }
         uint4 cc = c0;
         uint32_t lb = l0;
-        ma0 = mb0; ma1 = mb1;
+        ma0 = mb0; ma1 = mb1; ma2 = mb2;
         if (w + 1 < cnt) {
             prefetch(ma0, ma1);
             const int w2 = min(w + 2, cnt - 1);
-            mb0 = mq[2 * w2]; mb1 = mq[2 * w2 + 1];
+            mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
         }
         __syncthreads();
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
@@ -426,29 +455,32 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
             const uint4 cn = cp[jn];
             const uint32_t ln = lp[jn];
             const float l = lamtab[lb];
-            float s23 = 0.f, s4 = 0.f;
+            // PQScanMultiPassPrecomputed.cu:783-811 as written: dist = term1 + la*term6 + (la*la-la)*term5,
+            // then dist += term23[m] for m ascending; tmp += term4[m] from 0; result dist + la*tmp
+            float dist = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)), __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+            float tmp = 0.f;
             {
                 float va[8], vb[8];
                 VLQ_L16_LO(cc.x, cc.y);
 #pragma unroll
-                for (int m = 0; m < 8; m++) { s23 = __fadd_rn(s23, va[m]); s4 = __fadd_rn(s4, vb[m]); }
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, va[m]); tmp = __fadd_rn(tmp, vb[m]); }
             }
             {
                 float va[8], vb[8];
                 VLQ_L16_HI(cc.z, cc.w);
 #pragma unroll
-                for (int m = 0; m < 8; m++) { s23 = __fadd_rn(s23, va[m]); s4 = __fadd_rn(s4, vb[m]); }
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, va[m]); tmp = __fadd_rn(tmp, vb[m]); }
             }
-            const float head = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)),
-                                         __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
-            const float dist = __fadd_rn(__fadd_rn(head, s23), __fmul_rn(l, s4));
-            sel.offer(dist, pos0 + j, j < len);
+            dist = __fadd_rn(dist, __fmul_rn(l, tmp));
+            // positions do not arrive in increasing order (records are grouped by anchor): the full
+            // (distance, position) key decides among equal distances
+            sel.template offer<false>(dist, pos0 + j, j < len);
             cc = cn;
             lb = ln;
         }
-        pos0 += len;
+        total += len;
     }
-    if (t == 0) cum[cnt] = pos0;
+    if (t == 0) cum[cnt] = total;
 
     ScanArgs em;                 // only the fields merge_and_emit reads
     em.k = a.k;
@@ -458,12 +490,12 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
     em.D = a.D;
     em.I = a.I;
     if (cnt == 0 && t == 0) cum[1] = 0;
-    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane, [&](int w, int64_t& lkey, int64_t& loff) {
-        const uint4 m0 = mq[2 * w];
+    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane, [&](int rank, int64_t& lkey, int64_t& loff) {
+        const uint4 m0 = mq[3 * (int)wmap[rank]];
         lkey = (int64_t)(int32_t)m0.w;
         loff = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
     });
-    if (t == 0) atomicAdd(a.ncode, (unsigned long long)pos0);
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)total);
 }
 
 // ---------------------------------------------------------------------------
@@ -523,7 +555,9 @@ __global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_
             if (valid) {
                 const uint8_t* cj = cp + j * a.M;
                 const float l = a.lambda_info[lp[j]];
-                float s23 = 0.f, s4 = 0.f;
+                // the written order of PQScanMultiPassPrecomputed.cu:783-811 (see line16_scan_kernel)
+                float s23 = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)), __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+                float s4 = 0.f;
                 const float* p23 = t23;
                 const float* p4 = t4;
                 if ((a.M & 3) == 0) {
@@ -547,9 +581,7 @@ __global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_
                         p4 += a.ksub;
                     }
                 }
-                const float head = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)),
-                                             __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
-                dist = __fadd_rn(__fadd_rn(head, s23), __fmul_rn(l, s4));
+                dist = __fadd_rn(s23, __fmul_rn(l, s4));
             }
             sel.offer(dist, pos0 + (uint32_t)j, valid);
         }
@@ -586,7 +618,7 @@ void launch_line_scan(const LineScanArgs& a, hipStream_t s) {
     if (a.nq <= 0) return;
     if (a.M == 16 && a.ksub == 256 && a.sel_meta) {
         size_t lutb = (size_t)2 * 4096 * 4 + 256 * 4;      // T23, T4, lambda table; the merge area aliases T23/T4
-        const size_t smem16 = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + 16;
+        const size_t smem16 = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + ((size_t)a.w1 + 2) * 2 + 16;
         if (a.k <= 64) launch_line16_scan_t<1>(a, (int)lutb, smem16, s);
         else if (a.k <= 256) launch_line16_scan_t<4>(a, (int)lutb, smem16, s);
         else launch_line16_scan_t<16>(a, (int)lutb, smem16, s);

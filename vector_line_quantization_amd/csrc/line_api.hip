@@ -381,11 +381,13 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         TRY(coarse_page(b, ni, xi, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false, true));
         // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
         int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
+        // compact records (16-byte scan kernel): their sort key holds the candidate index in 24 bits
+        const bool with_meta = b->M == 16 && b->ksub == 256 && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
         vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
                                 h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
                                 sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream,
                                 h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
-                                h->ws_sel_meta.as<vlq::LineMeta>(), h->ws_sel_cnt.as<int32_t>());
+                                with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() : nullptr, h->ws_sel_cnt.as<int32_t>());
         // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
         vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
                               b->ws_qtab.as<float>(), b->stream);
@@ -396,7 +398,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
         a.lambda_info = h->lambda_info.as<float>();
         a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();
-        a.sel_meta = h->ws_sel_meta.as<vlq::LineMeta>(); a.sel_cnt = h->ws_sel_cnt.as<int32_t>();
+        a.sel_meta = with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() : nullptr; a.sel_cnt = h->ws_sel_cnt.as<int32_t>();
         a.D = (float*)Dd + i0 * k; a.I = (int64_t*)Id + i0 * k;
         a.ncode = h->stats.as<unsigned long long>();
         a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;

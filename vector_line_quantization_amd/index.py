@@ -26,6 +26,21 @@ def _ptr(a, np_dtype=None):
     return a.ctypes.data_as(C.c_void_p), a
 
 
+def _out_ptr(a, np_dtype):
+    """Pointer of an OUTPUT buffer: it must be written in place, so a buffer that would need a
+    contiguous (or dtype-converted) copy is an error, never a silent temporary."""
+    if _is_torch(a):
+        if not a.is_contiguous():
+            raise ValueError("output tensor must be contiguous (the library writes it in place)")
+        want = {np.float32: "torch.float32", np.int64: "torch.int64"}.get(np_dtype)
+        if want is not None and str(a.dtype) != want:
+            raise ValueError("output tensor must be %s, got %s" % (want, a.dtype))
+        return C.c_void_p(a.data_ptr()), a
+    if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"] or a.dtype != np.dtype(np_dtype) or not a.flags["WRITEABLE"]:
+        raise ValueError("output array must be a writeable C-contiguous numpy array of dtype %s" % np.dtype(np_dtype).name)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
 class GpuIVFPQ:
     """Mirror of the data-carrying surface of faiss::gpu::GpuIndexIVFPQ
     (gpu/GpuIndexIVFPQ.h:41-234) / faiss::IndexIVFPQ (IndexIVFPQ.h:29-164) for the
@@ -134,8 +149,8 @@ class GpuIVFPQ:
         px, _a = _ptr(x, np.float32)
         D = self._out(D, (n, k), np.float32, x)
         I = self._out(I, (n, k), np.int64, x)
-        pD, _b = _ptr(D)
-        pI, _c = _ptr(I)
+        pD, _b = _out_ptr(D, np.float32)
+        pI, _c = _out_ptr(I, np.int64)
         check(lib().vlq_ivfpq_search(self._h, C.c_int64(n), px, C.c_int(nprobe), C.c_int(k), pD, pI))
         return D, I
 
@@ -147,8 +162,8 @@ class GpuIVFPQ:
         pc, _c = _ptr(coarse_dis, np.float32)
         D = self._out(D, (n, k), np.float32, x)
         I = self._out(I, (n, k), np.int64, x)
-        pD, _d = _ptr(D)
-        pI, _e = _ptr(I)
+        pD, _d = _out_ptr(D, np.float32)
+        pI, _e = _out_ptr(I, np.int64)
         check(lib().vlq_ivfpq_search_preassigned(self._h, C.c_int64(n), px, pk, pc, C.c_int(nprobe),
                                                  C.c_int(k), pD, pI, C.c_int(int(store_pairs))))
         return D, I
@@ -158,8 +173,8 @@ class GpuIVFPQ:
         px, _a = _ptr(x, np.float32)
         cdis = self._out(cdis, (n, nprobe), np.float32, x)
         keys = self._out(keys, (n, nprobe), np.int64, x)
-        pc, _b = _ptr(cdis)
-        pk, _c = _ptr(keys)
+        pc, _b = _out_ptr(cdis, np.float32)
+        pk, _c = _out_ptr(keys, np.int64)
         check(lib().vlq_ivfpq_coarse_search(self._h, C.c_int64(n), px, C.c_int(nprobe), pc, pk))
         return cdis, keys
 
@@ -301,8 +316,8 @@ class GpuVLQ:
             D = GpuIVFPQ._out(self, None, (n, k), np.float32, x)
         if I is None:
             I = GpuIVFPQ._out(self, None, (n, k), np.int64, x)
-        pD, _b = _ptr(D)
-        pI, _c = _ptr(I)
+        pD, _b = _out_ptr(D, np.float32)
+        pI, _c = _out_ptr(I, np.int64)
         lines = np.empty((n, w1), np.int32) if return_lines else None
         pl = lines.ctypes.data_as(C.c_void_p) if return_lines else None
         check(lib().vlq_line_search(self._h, C.c_int64(n), px, C.c_int(nprobe), C.c_int(w1), C.c_int(k),
