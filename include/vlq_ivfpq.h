@@ -113,6 +113,15 @@ int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h);
 int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len);
 int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* ids_out);
 
+/* Scheduling of the 16-byte-code scan kernel -- SPEED ONLY, results are identical in every mode:
+ *   0  automatic (chosen per index when the coarse centroids are set)
+ *   1  query-major: one workgroup per query walks all its probes
+ *   2  list-owned: the lists are cut into 8 partitions of neighbouring lists, one per XCD; one workgroup
+ *      per (query, partition) scans the query's probes of that partition, a merge joins the parts.  Keeps
+ *      the term2 rows (IndexIVFPQ.cpp:641-644) of a partition in that XCD's L2.
+ * Replaces nothing in the reference (its CPU loop has no such choice). */
+int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode);
+
 /* IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) = GpuIndexIVFPQ::search.
  * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024. */
 int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k,

@@ -86,6 +86,9 @@ class OracleIndex:
         self.imi_centroids = None if imi_centroids is None else _f32(imi_centroids)
         if self.imi_nbits:
             coarse_centroids = np.zeros((1, d), np.float32)
+            if use_precomputed_table == 1:
+                # precompute_table() picks table type 2 for a MultiIndexQuantizer (IndexIVFPQ.cpp:396-408,430-457)
+                use_precomputed_table = 2
         self.ksub, self.dsub, self.code_size = 1 << nbits, d // M, M
         self.by_residual = bool(by_residual)
         self.use_precomputed_table = int(use_precomputed_table)

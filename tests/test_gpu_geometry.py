@@ -165,12 +165,14 @@ def vlq_c5():
     ei, ed = g.build_graph()                 # 65 536 x 64 graph on the device (parity: test_gpu_vlq.py)
     g.set_lambda_codebook(lam)
     g.set_pq_centroids(pq)
-    # database: 40 % spread over all centroids, 60 % crowded onto 300 of them (lines longer than the
-    # 1024-code cap, many empty lines); queries = perturbed members of the crowded part
+    # database: 30 % spread over all centroids, 40 % crowded onto 300 of them (8 edges each), 30 % onto
+    # 20 centroids x 2 edges (lines far longer than the 1024-code cap); most lines stay empty;
+    # queries = perturbed members of the crowded parts
     nb = 400000
     hot = rng.integers(0, nlist, 300)
-    pick = np.where(rng.random(nb) < 0.6, hot[rng.integers(0, 300, nb)], rng.integers(0, nlist, nb))
-    nbr = ei[pick, rng.integers(0, 8, nb)]    # towards one of the 8 nearest neighbours
+    u = rng.random(nb)
+    pick = np.where(u < 0.3, rng.integers(0, nlist, nb), np.where(u < 0.7, hot[rng.integers(0, 300, nb)], hot[rng.integers(0, 20, nb)]))
+    nbr = ei[pick, np.where(u < 0.7, rng.integers(0, 8, nb), rng.integers(0, 2, nb))]    # towards one of the nearest neighbours
     t = rng.random((nb, 1), dtype=np.float32) * 1.2 - 0.1
     xb = ((1 - t) * coarse[pick] + t * coarse[nbr] + 0.05 * rng.standard_normal((nb, d))).astype(np.float32)
     line, lb, codes = g.encode(xb)

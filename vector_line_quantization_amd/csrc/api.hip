@@ -277,6 +277,42 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         if (getenv("VLQ_PIPE")) a.long_lists = 1;
 #endif
         if (fast16) {
+            // scan schedule (speed only): list-owned = one workgroup per (query, list partition), XCD x
+            // serves the lists of partition x, so their term2 rows and codes stay in that XCD's L2
+            const int sched = h->scan_schedule ? h->scan_schedule : h->auto_schedule;
+            const bool owned = sched == 2 && h->imi_nbits == 0 && h->have_rank && h->nlist >= 64 && h->nlist <= 16384 &&
+                               ni >= 1024 && nprobe >= 8 && h->dsub == 8 && h->ntotal >= (int64_t)h->nlist * 24;
+            if (owned) {
+                TRY(h->ws_own_hist.reserve(vlq::owned_hist_ints(h->nlist) * sizeof(int)));
+                TRY(h->ws_own_minr.reserve((size_t)ni * 8 * sizeof(int)));
+                TRY(h->ws_own_order.reserve((size_t)ni * 8 * sizeof(int)));
+                TRY(h->ws_own_count.reserve(64));
+                TRY(h->ws_part_mask.reserve((size_t)ni + 16));
+                TRY(h->ws_part_keys.reserve((size_t)ni * 8 * k * 8));
+                TRY(h->ws_qtab.reserve((size_t)ni * E * sizeof(float)));
+                {
+                    StageTimer tq(h, 1);   // item ordering + per-query tables are booked with the table stage
+                    vlq::launch_owned_order(a.keys, ni, nprobe, h->nlist, h->list_rank.as<int>(), h->list_part.as<uint8_t>(),
+                                            h->ws_own_hist.as<int>(), h->ws_own_minr.as<int>(), h->ws_own_order.as<int>(),
+                                            h->ws_own_count.as<int>(), h->ws_part_mask.as<uint8_t>(), h->stream);
+                    vlq::launch_qtab16(xi, ni, h->pq_t.as<float>(), h->ws_qtab.as<float>(), h->stream);
+                    tq.stop();
+                }
+                vlq::ScanArgs ao = a;
+                ao.qorder = nullptr;
+                ao.qtab = h->ws_qtab.as<float>();
+                ao.qtab_scaled = 1;
+                ao.list_part = h->list_part.as<uint8_t>();
+                ao.own_order = h->ws_own_order.as<int>();
+                ao.own_count = h->ws_own_count.as<int>();
+                ao.part_mask = h->ws_part_mask.as<uint8_t>();
+                ao.part_keys = h->ws_part_keys.as<unsigned long long>();
+                StageTimer tm(h, 2);   // the scan of the items + the join of a query's parts
+                vlq::launch_scan16_owned(ao, h->stream);
+                vlq::launch_owned_merge(ao, h->stream);
+                tm.stop();
+                continue;
+            }
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);   // query ordering is booked with the table stage
                 // run queries that share their nearest centroid next to each other (L2 reuse)
@@ -398,6 +434,7 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
+    if (const char* e = getenv("VLQ_SCAN_SCHEDULE")) h->scan_schedule = atoi(e);   // tests / experiments: 1 query-major, 2 list-owned
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
     int rc = h->stats.reserve(16);
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
@@ -421,7 +458,8 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
-                      &h->list_off, &h->list_len, &h->list_rank, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->list_off, &h->list_len, &h->list_rank, &h->list_part, &h->ws_own_hist, &h->ws_own_minr, &h->ws_own_order,
+                      &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
@@ -520,6 +558,11 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
         spatial_list_rank(hc.data(), h->nlist, h->d, rank);
         TRY(h->list_rank.reserve((size_t)h->nlist * sizeof(int)));
         HIP_TRY(hipMemcpy(h->list_rank.p, rank.data(), (size_t)h->nlist * sizeof(int), hipMemcpyHostToDevice));
+        // 8 partitions of neighbouring lists (equal list counts along the spatial order), one per XCD
+        std::vector<uint8_t> part((size_t)h->nlist);
+        for (int i = 0; i < h->nlist; i++) part[(size_t)i] = (uint8_t)(((int64_t)rank[(size_t)i] * 8) / h->nlist);
+        TRY(h->list_part.reserve((size_t)h->nlist));
+        HIP_TRY(hipMemcpy(h->list_part.p, part.data(), (size_t)h->nlist, hipMemcpyHostToDevice));
         h->have_rank = true;
     }
     h->have_coarse = true;
@@ -587,6 +630,13 @@ int vlq_ivfpq_set_search_options(vlq_ivfpq_t h, int by_residual, int use_precomp
     h->by_residual = by_residual ? 1 : 0;
     h->use_precomputed_table = use_precomputed_table;
     h->max_codes = max_codes;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (mode < 0 || mode > 2) return fail(VLQ_ERR_INVALID, "scan schedule %d outside 0..2", mode);
+    h->scan_schedule = mode;
     return VLQ_OK;
 }
 

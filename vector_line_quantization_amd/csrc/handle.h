@@ -88,7 +88,13 @@ struct vlq_ivfpq_s {
     // inverted lists: list i at [list_off[i], list_off[i] + list_len[i]), capacity list_off[i+1] - list_off[i]
     DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off, list_len;
     DevBuf list_rank;             // [nlist] int: spatial order of the lists (query scheduling only)
+    DevBuf list_part;             // [nlist] u8: partition 0..7 of neighbouring lists, one per XCD (list-owned schedule)
     bool have_rank = false;
+    // scan schedule of the 16-byte kernel: 0 = automatic, 1 = one workgroup per query (query-major),
+    // 2 = list-owned (one workgroup per (query, list partition)).  Speed only, never results.
+    int scan_schedule = 0;
+    int auto_schedule = 1;        // what "automatic" resolved to for this index (set with the centroids)
+    DevBuf ws_own_hist, ws_own_minr, ws_own_order, ws_own_count, ws_part_mask, ws_part_keys;
     // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,
     // and the kc virtual full vectors whose term2 rows make table type 2
     int imi_nbits = 0;

@@ -69,10 +69,30 @@ struct ScanArgs {
     int nsplit = 1;              // scan16: workgroups per query; > 1: D / I are [nsplit][nq][k] partial rows
     int long_lists = 0;          // scan16: mean list length >= 4 chunks -- selects the pipelined pair loop for k > 64 too
     int xcd_chunk = 0;           // set by the launcher
+    // list-owned schedule (scan16 only, DESIGN.md "list-owned schedule"): the lists are cut into 8
+    // partitions of neighbouring lists, one per XCD; a workgroup serves the probes of ONE query that fall
+    // into ONE partition and leaves its k best raw keys (ordered distance << 32 | scan position) in
+    // part_keys [nq][8][k]; owned_merge joins a query's parts in the global (distance, position) order
+    const uint8_t* list_part = nullptr;      // [nlist] partition 0..7 of every list
+    const int* own_order = nullptr;          // [8][nq] the queries with probes in partition x, scheduling order
+    const int* own_count = nullptr;          // [8]
+    unsigned long long* part_keys = nullptr; // [nq][8][k]
+    const uint8_t* part_mask = nullptr;      // [nq] bit x: the query has a probe in partition x
+    int qtab_scaled = 0;                     // qtab already holds (-2) * <q_m, cent_mj>
 };
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
+// list-owned schedule of the same kernel: launch_owned_order prepares own_order / own_count / part_mask,
+// launch_qtab16 the per-query table (-2 <q_m, cent_mj>, [nq][16][256]), launch_scan16_owned scans the
+// (query, partition) items and launch_owned_merge writes the final rows
+void launch_owned_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, const int* list_rank,
+                        const uint8_t* list_part, int* hist /* [2][8][nlist] + 8 */, int* minr /* [nq][8] */,
+                        int* own_order, int* own_count, uint8_t* part_mask, hipStream_t s);
+inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
+void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
+void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
+void launch_owned_merge(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
 void launch_scan16_short(const ScanArgs& a, hipStream_t s);
 // second generation: whole-probe prefetch, scalar list bases (scan16v2.hip)

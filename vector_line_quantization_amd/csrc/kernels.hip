@@ -752,25 +752,28 @@ void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, 
 // ---------------------------------------------------------------------------
 constexpr int kTableVT = 32;
 
+// blockIdx.z: chunk of kch centroids (a 16 384-entry multi-index half table does not fit LDS at once)
 __global__ __launch_bounds__(256) void pq_tables_kernel(
     const float* __restrict__ x, int64_t nv, int d, const float* __restrict__ cent, int M,
-    int ksub, int dsub, const float* __restrict__ rnorm, int mode, float* __restrict__ out) {
+    int ksub, int dsub, const float* __restrict__ rnorm, int mode, float* __restrict__ out, int kch) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ds1 = dsub + 1;
-    float* scent = sm;                  // [ksub][dsub+1]
-    float* sx = sm + ksub * ds1;        // [VT][dsub]
+    float* scent = sm;                  // [kch][dsub+1]
+    float* sx = sm + kch * ds1;         // [VT][dsub]
     const int m = blockIdx.y;
+    const int j0 = blockIdx.z * kch;
+    const int nj = min(kch, ksub - j0);
     const int64_t v0 = (int64_t)blockIdx.x * kTableVT;
     const int t = threadIdx.x;
-    const float* cm = cent + (size_t)m * ksub * dsub;
-    for (int e = t; e < ksub * dsub; e += 256) scent[(e / dsub) * ds1 + (e % dsub)] = cm[e];
+    const float* cm = cent + ((size_t)m * ksub + j0) * dsub;
+    for (int e = t; e < nj * dsub; e += 256) scent[(e / dsub) * ds1 + (e % dsub)] = cm[e];
     for (int e = t; e < kTableVT * dsub; e += 256) {
         const int64_t v = v0 + e / dsub;
         sx[e] = v < nv ? x[v * d + m * dsub + (e % dsub)] : 0.f;
     }
     __syncthreads();
-    for (int e = t; e < kTableVT * ksub; e += 256) {
-        const int vl = e / ksub, j = e % ksub;
+    for (int e = t; e < kTableVT * nj; e += 256) {
+        const int vl = e / nj, j = e % nj;
         const int64_t v = v0 + vl;
         if (v >= nv) break;
         const float* xv = sx + vl * dsub;
@@ -781,19 +784,23 @@ __global__ __launch_bounds__(256) void pq_tables_kernel(
         } else {
             r = ip_sse_order([&](int c) { return xv[c]; }, [&](int c) { return cj[c]; }, dsub);
             if (mode == 2)  // fvec_madd(r_norms, 2.0, tab): a + bf*b (utils.cpp:1832-1853)
-                r = __fadd_rn(rnorm[m * ksub + j], __fmul_rn(2.f, r));
+                r = __fadd_rn(rnorm[m * ksub + j0 + j], __fmul_rn(2.f, r));
         }
-        out[((size_t)v * M + m) * ksub + j] = r;
+        out[((size_t)v * M + m) * ksub + j0 + j] = r;
     }
 }
 
 void launch_pq_tables(const float* x, int64_t nv, int d, const float* cent, int M, int ksub,
                       int dsub, const float* rnorm, int mode, float* out, hipStream_t s) {
     if (nv <= 0) return;
-    const size_t smem = ((size_t)ksub * (dsub + 1) + (size_t)kTableVT * dsub) * sizeof(float);
-    dim3 grid((unsigned)((nv + kTableVT - 1) / kTableVT), (unsigned)M);
+    // centroids of one chunk + the vectors' sub-vectors in at most 64 KB of LDS
+    int kch = ksub;
+    while ((size_t)kch * (dsub + 1) * sizeof(float) > 60 * 1024 && kch > 64) kch = (kch + 1) / 2;
+    const size_t smem = ((size_t)kch * (dsub + 1) + (size_t)kTableVT * dsub) * sizeof(float);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(pq_tables_kernel), smem);
+    dim3 grid((unsigned)((nv + kTableVT - 1) / kTableVT), (unsigned)M, (unsigned)((ksub + kch - 1) / kch));
     hipLaunchKernelGGL(pq_tables_kernel, grid, dim3(256), smem, s, x, nv, d, cent, M, ksub, dsub,
-                       rnorm, mode, out);
+                       rnorm, mode, out, kch);
 }
 
 // ---------------------------------------------------------------------------

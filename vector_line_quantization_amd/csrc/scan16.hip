@@ -24,7 +24,8 @@ namespace vlq {
 
 // IMI: table type 2 (multi-index: two term2 rows per list) -- a compile-time switch, the row
 // addressing sits in the per-probe prefetch
-template <int KPL, int NW, int NBUF, bool PIPE, bool IMI>
+// OWNED: the list-owned schedule (kernels.h): the workgroup is one (query, list partition) item
+template <int KPL, int NW, int NBUF, bool PIPE, bool IMI, bool OWNED = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL == 4 || KPL == 2) && PIPE) ? 4 : 1))) void scan16_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096;
     constexpr int NT = 64 * NW;       // threads per workgroup
@@ -50,8 +51,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
     // small batches: a query's probes are split over a.nsplit workgroups (parts = contiguous ranges
     // of the walking order) that write partial top-k rows [part][nq][k]; merge_topk_kernel joins them
     int64_t q;
-    int part = 0;
-    {
+    int part = 0, own_x = 0;
+    if (OWNED) {
+        // consecutive workgroups go round-robin over the 8 XCDs: XCD x serves partition x, its items in
+        // the order launch_owned_order gave them (neighbouring lists next to each other in time)
+        const int64_t b = blockIdx.x;
+        own_x = (int)(b & 7);
+        const int64_t slot = b >> 3;
+        if (slot >= a.own_count[own_x]) return;
+        q = a.own_order[(int64_t)own_x * a.nq + slot];
+    } else {
         const int64_t b = blockIdx.x;
         const int64_t s = (b & 7) * a.xcd_chunk + (b >> 3);
         if (s >= a.nq * a.nsplit) return;
@@ -72,7 +81,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         int nl = 0;
         for (int p0 = 0; p0 < cut; p0 += 64) {      // coarse-distance order, dead probes dropped
             const int p = p0 + lane;
-            const bool lv = p < cut && pm.pkey[p] >= 0;
+            bool lv = p < cut && pm.pkey[p] >= 0;
+            if (OWNED) lv = lv && a.list_part[pm.pkey[p]] == own_x;      // this item's share of the probes
             const u64 mask = __ballot(lv);
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
@@ -203,10 +213,187 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         if (NBUF == 2) buf ^= 1;
     }
 
-    merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
-                        [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
+    if (OWNED) {
+        // raw keys out: scan positions are global to the query, so owned_merge_kernel can order the
+        // parts' candidates exactly like one workgroup scanning all probes would have
+        if (merge_waves<KPL, NW, QR>(sel, smraw, a.k, wave, lane)) {
+            u64* out = a.part_keys + ((size_t)q * 8 + own_x) * a.k;
+#pragma unroll
+            for (int r = 0; r < KPL; r++) {
+                const int e = r * 64 + lane;
+                if (e < a.k) out[e] = sel.best[r];
+            }
+        }
+    } else {
+        merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
+                                    [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
+    }
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
     if (badkey) *a.bad_key = 1;
+}
+
+// joins the parts of the list-owned schedule: one wave per query rebuilds the query's probe metadata
+// (the same prefix sums and max_codes cut every item used), selects the k smallest of its parts' keys
+// -- a total order (distance, scan position), so the result is what one workgroup scanning all probes
+// returns -- and translates positions to ids
+template <int KPL>
+__global__ __launch_bounds__(256) void owned_merge_kernel(ScanArgs a, int stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= a.nq) return;                      // (no workgroup barrier below)
+    unsigned char* base = smraw + (size_t)wave * stride;
+    u64* queue = reinterpret_cast<u64*>(base);                       // [64]
+    ProbeMeta pm;
+    pm.carve(base + 512, a.nprobe);
+    const int64_t* kq = a.keys + q * a.nprobe;
+    probe_meta_fill(a, q, pm, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    probe_meta_scan(a, pm, lane);
+    __builtin_amdgcn_wave_barrier();
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue, lane);
+    const uint32_t m = a.part_mask[q];
+    for (int x = 0; x < 8; x++) {
+        if (!((m >> x) & 1u)) continue;
+        const u64* src = a.part_keys + ((size_t)q * 8 + x) * a.k;
+        for (int e0 = 0; e0 < a.k; e0 += 64) {
+            const int e = e0 + lane;
+            const bool valid = e < a.k;
+            sel.offer_key(valid ? src[e] : kMaxKey, valid);
+        }
+    }
+    sel.flush();
+    emit_rows<KPL>(sel, pm.cum, a, q, lane, [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
+}
+
+void launch_owned_merge(const ScanArgs& a, hipStream_t s) {
+    if (a.nq <= 0) return;
+    const int stride = (int)((512 + (size_t)a.nprobe * 24 + 8 + 15) & ~(size_t)15);
+    const size_t smem = (size_t)4 * stride;
+    dim3 grid((unsigned)((a.nq + 3) / 4)), block(256);
+#define VLQ_OM(K)                                                                                  \
+    do {                                                                                           \
+        ensure_dynamic_lds(reinterpret_cast<const void*>(owned_merge_kernel<K>), smem);            \
+        hipLaunchKernelGGL(owned_merge_kernel<K>, grid, block, smem, s, a, stride);                \
+    } while (0)
+    if (a.k <= 64) VLQ_OM(1);
+    else if (a.k <= 128) VLQ_OM(2);
+    else if (a.k <= 256) VLQ_OM(4);
+    else if (a.k <= 512) VLQ_OM(8);
+    else VLQ_OM(16);
+#undef VLQ_OM
+}
+
+// ---------------------------------------------------------------------------
+// list-owned schedule, preparation: for every query the partitions its probes fall into, and per
+// partition the queries in the order of the spatial rank of their NEAREST list of that partition.
+// Ordering only decides which items run next to each other; never a result.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void owned_hist_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
+                                                         int nlist, const int* __restrict__ list_rank,
+                                                         const uint8_t* __restrict__ list_part, int* __restrict__ hist,
+                                                         int* __restrict__ minr, uint8_t* __restrict__ part_mask) {
+    __shared__ int mr[256][9];                 // (row stride 9: bank-conflict free)
+    const int t = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 256 + t;
+    if (q >= nq) return;
+#pragma unroll
+    for (int x = 0; x < 8; x++) mr[t][x] = 0x7fffffff;
+    for (int p = 0; p < nprobe; p++) {
+        const int64_t key = keys[q * nprobe + p];
+        if (key < 0 || key >= nlist) continue;
+        const int x = list_part[key], r = list_rank[key];
+        if (r < mr[t][x]) mr[t][x] = r;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+        const int r = mr[t][x];
+        minr[q * 8 + x] = r;
+        if (r != 0x7fffffff) { m |= 1u << x; atomicAdd(&hist[(size_t)x * nlist + r], 1); }
+    }
+    part_mask[q] = (uint8_t)m;
+}
+
+__global__ __launch_bounds__(256) void owned_place_kernel(int64_t nq, int nlist, const int* __restrict__ hist,
+                                                          int* __restrict__ cnt, const int* __restrict__ minr,
+                                                          int* __restrict__ own_order, int* __restrict__ own_count) {
+    extern __shared__ int pre[];                 // [nlist] exclusive prefix of this partition's bins
+    __shared__ int part[256];
+    const int t = threadIdx.x, x = blockIdx.y;
+    const int* hx = hist + (size_t)x * nlist;
+    const int per = (nlist + 255) / 256;
+    const int b0 = t * per;
+    int sum = 0;
+    for (int i = 0; i < per; i++) if (b0 + i < nlist) sum += hx[b0 + i];
+    part[t] = sum;
+    __syncthreads();
+    for (int sft = 1; sft < 256; sft <<= 1) {
+        const int v = t >= sft ? part[t - sft] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < nlist) { pre[b0 + i] = run; run += hx[b0 + i]; }
+    if (blockIdx.x == 0 && t == 255) own_count[x] = part[255];
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * 256 + t;
+    if (q >= nq) return;
+    const int r = minr[q * 8 + x];
+    if (r == 0x7fffffff) return;
+    own_order[(int64_t)x * nq + pre[r] + atomicAdd(&cnt[(size_t)x * nlist + r], 1)] = (int)q;
+}
+
+void launch_owned_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, const int* list_rank,
+                        const uint8_t* list_part, int* hist, int* minr, int* own_order, int* own_count,
+                        uint8_t* part_mask, hipStream_t s) {
+    if (nq <= 0) return;
+    (void)hipMemsetAsync(hist, 0, (size_t)16 * nlist * sizeof(int), s);     // hist | cnt
+    const unsigned g = (unsigned)((nq + 255) / 256);
+    hipLaunchKernelGGL(owned_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, list_rank, list_part,
+                       hist, minr, part_mask);
+    const size_t smem = (size_t)nlist * sizeof(int);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(owned_place_kernel), smem);
+    hipLaunchKernelGGL(owned_place_kernel, dim3(g, 8), dim3(256), smem, s, nq, nlist, hist, hist + (size_t)8 * nlist,
+                       minr, own_order, own_count);
+}
+
+// per-query table of the list-owned schedule: out[q][m][j] = (-2) * <q_m, cent_mj> with exactly the
+// operations of load_query_table16's fused form (fvec_inner_product order, utils.cpp:509-533).  A
+// workgroup keeps one quarter of the transposed codebook in registers and runs over QB queries.
+__global__ __launch_bounds__(256) void qtab16_kernel(const float* __restrict__ queries, int64_t nq,
+                                                     const float* __restrict__ pq_cent_t, float* __restrict__ qtab) {
+    constexpr int QB = 16;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i = blockIdx.y;                   // quarter: sub-quantizers 4*i .. 4*i+3, one per wave
+    const int m = 4 * i + wave;
+    const float4* ct = reinterpret_cast<const float4*>(pq_cent_t + (size_t)m * 8 * 256) + lane;
+    const float4 y0 = ct[0 * 64], y1 = ct[1 * 64], y2 = ct[2 * 64], y3 = ct[3 * 64];
+    const float4 y4 = ct[4 * 64], y5 = ct[5 * 64], y6 = ct[6 * 64], y7 = ct[7 * 64];
+    const int64_t q0 = (int64_t)blockIdx.x * QB;
+    for (int qi = 0; qi < QB; qi++) {
+        const int64_t q = q0 + qi;
+        if (q >= nq) break;
+        const float* qv = queries + q * 128;
+        const float4 x0 = *reinterpret_cast<const float4*>(qv + m * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(qv + m * 8 + 4);
+#define VLQ_IP8(C)                                                                                        \
+    __fmul_rn(-2.f,                                                                                      \
+              __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.x, y0.C)), __fmul_rn(x1.x, y4.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.y, y1.C)), __fmul_rn(x1.y, y5.C)), 0.f)), \
+                        __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.z, y2.C)), __fmul_rn(x1.z, y6.C)), 0.f), \
+                                  __fadd_rn(__fadd_rn(__fadd_rn(0.f, __fmul_rn(x0.w, y3.C)), __fmul_rn(x1.w, y7.C)), 0.f))))
+        reinterpret_cast<float4*>(qtab + q * 4096)[i * 256 + t] = make_float4(VLQ_IP8(x), VLQ_IP8(y), VLQ_IP8(z), VLQ_IP8(w));
+#undef VLQ_IP8
+    }
+}
+
+void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(qtab16_kernel, dim3((unsigned)((nq + 15) / 16), 4), dim3(256), 0, s, queries, nq, pq_cent_t, qtab);
 }
 
 // ---------------------------------------------------------------------------
@@ -343,14 +530,22 @@ static void launch_scan16_i(const ScanArgs& a, int lut_region, size_t smem, hipS
 }
 template <int KPL, int NW, int NBUF, bool PIPE>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
+    if (a.part_keys) {        // list-owned schedule: 8 x nq slots, the surplus exits at once
+        ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE, false, true>), smem);
+        hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE, false, true>), dim3((unsigned)(8 * a.nq)), dim3(64 * NW), smem, s,
+                           a, lut_region);
+        return;
+    }
     if (a.imi_nbits > 0) launch_scan16_i<KPL, NW, NBUF, PIPE, true>(a, lut_region, smem, s);
     else launch_scan16_i<KPL, NW, NBUF, PIPE, false>(a, lut_region, smem, s);
 }
 
+void launch_scan16_owned(const ScanArgs& a, hipStream_t s) { launch_scan16(a, s); }
+
 void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     if (a_in.nq <= 0) return;
     ScanArgs a = a_in;
-    if (a.nsplit < 1) a.nsplit = 1;
+    if (a.nsplit < 1 || a.part_keys) a.nsplit = 1;
     a.xcd_chunk = (int)((a.nq * a.nsplit + 7) / 8);
     // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
     // larger k keeps more selection state per wave, so stay at 4 waves

@@ -20,8 +20,9 @@ __device__ __forceinline__ void load_query_table16(const ScanArgs& a, int64_t q,
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             const float4 v = qt[i * NT + t];
-            m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
-                                  __fmul_rn(-2.f, v.w));
+            m2t3[i] = a.qtab_scaled ? v
+                                    : make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z),
+                                                  __fmul_rn(-2.f, v.w));
         }
     } else {
         // codebook read from its transposed copy pq_cent_t[m][component][j]: the four

@@ -8,29 +8,11 @@
 
 namespace vlq {
 
-// resolve(p, lkey, loff): list id and list start offset of probe p
-template <int KPL, int NW = 4, int QR = 1, typename Sel, typename Resolve>
-__device__ __forceinline__ void merge_and_emit(Sel& sel, unsigned char* smraw,
-                                               const uint32_t* cum, const ScanArgs& a, int64_t q,
-                                               int wave, int lane, Resolve resolve) {
-    sel.flush();
-    __syncthreads();                           // LUT buffers are free from here on
-    u64* mb = reinterpret_cast<u64*>(smraw);   // [NW][k], aliases the LUT
-#pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const int e = r * 64 + lane;
-        if (e < a.k) mb[wave * a.k + e] = sel.best[r];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < NW; w++)
-        for (int e0 = 0; e0 < a.k; e0 += 64) {
-            const int e = e0 + lane;
-            const bool valid = e < a.k;
-            const u64 key = valid ? mb[w * a.k + e] : kMaxKey;
-            sel.offer_key(key, valid);
-        }
-    sel.flush();
+// Rows out: the selection's sorted keys -> (distance, label).  Scan positions are translated with
+// the prefix sums `cum`; resolve(p, lkey, loff): list id and list start offset of probe p.
+template <int KPL, typename Sel, typename Resolve>
+__device__ __forceinline__ void emit_rows(const Sel& sel, const uint32_t* cum, const ScanArgs& a, int64_t q,
+                                          int lane, Resolve resolve) {
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const int e = r * 64 + lane;
@@ -54,6 +36,39 @@ __device__ __forceinline__ void merge_and_emit(Sel& sel, unsigned char* smraw,
         a.D[q * a.k + e] = dis;
         a.I[q * a.k + e] = id;
     }
+}
+
+// joins the NW waves' selections in wave 0 (its `sel` then holds the workgroup's k best keys);
+// returns true in wave 0 only
+template <int KPL, int NW = 4, int QR = 1, typename Sel>
+__device__ __forceinline__ bool merge_waves(Sel& sel, unsigned char* smraw, int k, int wave, int lane) {
+    sel.flush();
+    __syncthreads();                           // LUT buffers are free from here on
+    u64* mb = reinterpret_cast<u64*>(smraw);   // [NW][k], aliases the LUT
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < k) mb[wave * k + e] = sel.best[r];
+    }
+    __syncthreads();
+    if (wave != 0) return false;
+    for (int w = 1; w < NW; w++)
+        for (int e0 = 0; e0 < k; e0 += 64) {
+            const int e = e0 + lane;
+            const bool valid = e < k;
+            const u64 key = valid ? mb[w * k + e] : kMaxKey;
+            sel.offer_key(key, valid);
+        }
+    sel.flush();
+    return true;
+}
+
+template <int KPL, int NW = 4, int QR = 1, typename Sel, typename Resolve>
+__device__ __forceinline__ void merge_and_emit(Sel& sel, unsigned char* smraw,
+                                               const uint32_t* cum, const ScanArgs& a, int64_t q,
+                                               int wave, int lane, Resolve resolve) {
+    if (!merge_waves<KPL, NW, QR>(sel, smraw, a.k, wave, lane)) return;
+    emit_rows<KPL>(sel, cum, a, q, lane, resolve);
 }
 
 }  // namespace vlq
