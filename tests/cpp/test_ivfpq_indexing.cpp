@@ -11,6 +11,7 @@
 #include "faiss_amd/IndexIVFPQ.h"
 #include "faiss_amd/gpu/GpuClonerOptions.h"
 #include "faiss_amd/gpu/GpuIndexIVFPQ.h"
+#include "faiss_amd/gpu/IndexProxy.h"
 #include "faiss_amd/gpu/StandardGpuResources.h"
 #include "faiss_amd/index_io.h"
 
@@ -197,6 +198,32 @@ int main() {
     faiss::gpu::GpuMultipleClonerOptions mco;
     EXPECT(!mco.shard && mco.usePrecomputed);
     printf("part 2e: reference driver configuration (useFloat16LookupTables, INDICES_CPU) accepted, answers equal fp32\n");
+  }
+
+  // part 2f: faiss::gpu::IndexProxy (gpu/IndexProxy.cpp:123-168) over GPU replicas: one replica = the
+  // index itself; two replicas (both on device 0 here: a one-GPU box) searched from two host threads at
+  // once -- slices written straight into the caller's buffers, answers identical to one index
+  {
+    faiss::gpu::GpuIndexIVFPQ rep0(&res, &index, config), rep1(&res, &index, config);
+    rep0.setNumProbes(5);
+    rep1.setNumProbes(5);
+    for (int nrep = 1; nrep <= 2; nrep++) {
+      faiss::gpu::IndexProxy proxy;
+      proxy.addIndex(&rep0);
+      if (nrep == 2) proxy.addIndex(&rep1);
+      std::vector<faiss::Index::idx_t> pn((size_t)k * nq, -7);
+      std::vector<float> pd((size_t)k * nq, -7.f);
+      for (int rep = 0; rep < 3; rep++) proxy.search(nq, queries.data(), k, pd.data(), pn.data());
+      EXPECT(pn == nns && pd == dis);
+      EXPECT(proxy.count() == nrep && proxy.ntotal == (faiss::Index::idx_t)nb && proxy.d == d);
+      // fewer queries than replicas (the <20-query coarse path: compare with the replica itself)
+      std::vector<faiss::Index::idx_t> one_n(k), one_p(k);
+      std::vector<float> one_d(k), one_pd(k);
+      proxy.search(1, queries.data(), k, one_pd.data(), one_p.data());
+      rep0.search(1, queries.data(), k, one_d.data(), one_n.data());
+      EXPECT(one_p == one_n && one_pd == one_d);
+    }
+    printf("part 2f: IndexProxy over 1 and 2 GPU replicas answers like one index\n");
   }
 
   // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of

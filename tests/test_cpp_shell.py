@@ -21,6 +21,14 @@ def test_shell_compiles_and_links():
     assert os.access(exe, os.X_OK)
 
 
+def test_index_proxy_host_logic():
+    """faiss::gpu::IndexProxy (the C++ multi-GPU replica host): slicing, threads, fan-out and errors with
+    stub replicas -- no GPU needed."""
+    _build()
+    p = subprocess.run([os.path.join(CPP, "test_index_proxy")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "all ok" in p.stdout, p.stdout + p.stderr
+
+
 def test_shell_fails_loudly_without_gpu():
     import vector_line_quantization_amd as vlq
     if vlq.device_count() > 0:

@@ -58,12 +58,37 @@ def test_full_batch_vs_compiled_reference(world, tmp_path):
     D, I = world["D"], world["I"]
     assert meta[0] == 1
     from util import label_agreement
-    assert label_agreement(D[::7], I[::7], Dr[::7], Ir[::7]) >= 0.999
+    # the BLAS coarse stage (MKL sgemm) may round a probe boundary differently from the k-ordered MFMA
+    # chain (unpinned by construction): rows whose probe sets agree -- decided by the
+    # row's distances agreeing bit for bit -- must agree in EVERY slot; the others are counted and bounded
+    row_eq = (D.view(np.uint32) == Dr.view(np.uint32)).all(axis=1)
+    assert row_eq.mean() >= 0.999, row_eq.mean()
+    assert label_agreement(D[row_eq], I[row_eq], Dr[row_eq], Ir[row_eq]) == 1.0
     same = I == Ir
-    assert same.mean() > 0.9
     rel = np.abs(D[same] - Dr[same]) / np.maximum(np.abs(Dr[same]), 1e-20)
-    assert rel.max() <= 1e-4
-    assert (D.view(np.uint32) == Dr.view(np.uint32)).mean() > 0.999
+    assert rel.max() <= 1e-4                                        # north-star tolerance where labels agree
+
+
+def test_host_buffers_device_buffers_and_schedules_agree(world):
+    """The same 10 000 queries through the paged host-buffer path (numpy in / out: three pages, copies
+    overlapped with the search), through device buffers, and under the list-owned schedule: one answer."""
+    import torch
+    g, xq = world["g"], world["xq"]
+    xd = torch.from_numpy(xq).cuda()
+    Dd, Id = g.search(xd, NPROBE, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(Dd.cpu().numpy()), bits(world["D"])) and np.array_equal(Id.cpu().numpy(), world["I"])
+    g.set_scan_schedule(2)
+    try:
+        Do, Io = g.search(xq, NPROBE, K)
+        Dod, Iod = g.search(xd, NPROBE, 100)
+        g.set_scan_schedule(1)
+        Dq, Iq = g.search(xd, NPROBE, 100)
+        torch.cuda.synchronize()
+    finally:
+        g.set_scan_schedule(0)
+    assert np.array_equal(bits(Do), bits(world["D"])) and np.array_equal(Io, world["I"])
+    assert torch.equal(Dod, Dq) and torch.equal(Iod, Iq)
 
 
 def test_ncode_counter_matches_list_lengths(world):
