@@ -16,7 +16,8 @@ g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run i
 t0 = time.time()
 g.set_coarse_centroids(centres)
 print("set_coarse_centroids (incl. spatial rank of %d lists): %.1f s" % (nlist, time.time() - t0), flush=True)
-g.set_pq_centroids(((torch.rand((M, 256, d // M), generator=gen, device=dev) - 0.5) * 0.1).contiguous())
+pq_t = ((torch.rand((M, 256, d // M), generator=gen, device=dev) - 0.5) * 0.1).contiguous()
+g.set_pq_centroids(pq_t)
 def batch(i, n):
     gb = torch.Generator(device=dev); gb.manual_seed(1000 + i)
     pick = torch.randint(0, nlist, (n,), generator=gb, device=dev)
@@ -53,3 +54,12 @@ self_hit = float((Ih[:, 0] == np.arange(nq)).mean())
 self_in = float((Ih == np.arange(nq)[:, None]).any(axis=1).mean())
 print("search: %.3f ms per %d queries = %.2f M queries/s, %.0f codes per query, self-hit@1 %.3f, self in top-%d %.3f" % (
     dt * 1e3, nq, nq / dt / 1e6, ncode / 5 / nq, self_hit, k, self_in))
+
+# ---- verification (outside every timed region): a query sample against the oracle on the probed lists ----
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import scale_checks
+res = scale_checks.check_ivfpq_sample(g, xq[:int(os.environ.get("CHECK", 8))].cpu().numpy(), nprobe, k, pq_t.cpu().numpy(),
+                                      coarse=centres.cpu().numpy())
+print("oracle sample check:", res, flush=True)
+assert self_hit >= 0.99 and res["ok"], "verification failed"
+print("VERIFIED")

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""VLQ (line quantization) search timing on synthetic data (kernel experiments).
-   python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D"""
+"""VLQ (line quantization) at the reference driver's geometry (NLIST=65536 NEDGE=64
+NB=1000000000): build on the device, time the search, and VERIFY it -- a sample of queries is checked
+bit for bit against the VLQ oracle on the lines it selects, fetched back from the device, and stored
+vectors used as queries must come back (tests/scale_checks.py).
+   python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D, CHECK (sample size, default 6)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,9 +20,11 @@ g = vlq.GpuVLQ(d, nlist, M, 8, nedge, 256)
 g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 cent = rng.random((nlist, d), dtype=np.float32)
 g.set_coarse_centroids(cent)
-g.build_graph()
-g.set_lambda_codebook(np.linspace(-0.2, 1.2, 256).astype(np.float32))
-g.set_pq_centroids((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2)
+ei, ed = g.build_graph()
+lam = np.linspace(-0.2, 1.2, 256).astype(np.float32)
+g.set_lambda_codebook(lam)
+pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+g.set_pq_centroids(pq)
 t0 = time.time()
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
 step = 1000000
@@ -27,11 +32,14 @@ for i in range(0, nb, step):
     n = min(step, nb - i)
     pick = torch.randint(0, nlist, (n,), device="cuda", generator=gen)
     x = torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((n, d), device="cuda", generator=gen)
+    if i == 0: first = x[:nq].clone()                   # stored vectors 0 .. nq-1 (sequential ids)
     g.add(x.contiguous())
 torch.cuda.synchronize()
 print("added %d vectors in %.1f s (%d lines, %.1f per line)" % (nb, time.time() - t0, nlist * nedge, nb / (nlist * nedge)), flush=True)
 pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
 xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
+nself = min(nq, first.shape[0]) // 2
+xq[:nself] = first[:nself]                              # half the batch: stored vectors
 D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
 I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
 for _ in range(2):
@@ -46,3 +54,16 @@ dt = (time.time() - t0) / reps
 ncode = g.stats() / reps
 print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s (17 B/code)" % (
     dt * 1e3, nq, nq / dt, ncode / nq, ncode * 17 / dt / 1e9))
+
+# ---- verification (outside every timed region) ----
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import scale_checks
+Ih = I.cpu().numpy()
+s1, sk = scale_checks.self_hit(Ih[:nself])
+print("self-hit: %d stored vectors as queries: first %.4f, in top-%d %.4f" % (nself, s1, k, sk), flush=True)
+ns = E("CHECK", 6)
+pick = np.r_[0:ns // 2, nself:nself + ns - ns // 2]
+res = scale_checks.check_vlq_sample(g, xq[pick].cpu().numpy(), nprobe, w1, k, cent, pq, lam, ei, ed)
+print("oracle sample check:", res, flush=True)
+assert sk >= 0.9 and res["ok"], "verification failed"
+print("VERIFIED")

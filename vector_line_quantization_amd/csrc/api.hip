@@ -348,6 +348,8 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                     ap.I = h->ws_Ip.as<int64_t>();
                     vlq::launch_scan16(ap, h->stream);
                     vlq::launch_merge_topk(ap.D, ap.I, ni, k, nsplit, a.D, a.I, h->stream);
+                } else if (k > 256) {
+                    vlq::launch_scan16_bigk(a, h->stream);      // one selection per workgroup
                 } else {
                     vlq::launch_scan16(a, h->stream);
                 }

@@ -93,6 +93,8 @@ inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
 void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
 void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
 void launch_owned_merge(const ScanArgs& a, hipStream_t s);
+// same shape, 256 < k <= 1024: one selection per workgroup instead of one per wave (scan16k.hip)
+void launch_scan16_bigk(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
 void launch_scan16_short(const ScanArgs& a, hipStream_t s);
 // second generation: whole-probe prefetch, scalar list bases (scan16v2.hip)
