@@ -34,7 +34,7 @@ struct GpuIndexIVFConfig : public GpuIndexConfig {
 };
 struct GpuIndexIVFPQConfig : public GpuIndexIVFConfig {
   GpuIndexIVFPQConfig() : useFloat16LookupTables(false), usePrecomputedTables(false) {}
-  bool useFloat16LookupTables;  ///< accepted; tables stay fp32 here (superset precision, bit parity with the CPU index)
+  bool useFloat16LookupTables;  ///< VLQ search (16 x 8 bit): half tables as in the reference; IVFPQ search: fp32 (superset precision)
   bool usePrecomputedTables;
 };
 
@@ -89,6 +89,10 @@ class GpuIndexIVFPQ : public GpuIndex {
     is_trained = false;
     VLQ_CHECK(vlq_line_create(&line_, device_, d, nlist_, subQuantizers_, bitsPerCode_, numedge_, nLambda_));
     VLQ_CHECK(vlq_line_set_stream(line_, (void*)resources_->getDefaultStream(device_)));
+    // the VLQ search honours float16 look-up tables for the drivers' shape (16 x 8-bit codes), built as the
+    // reference builds them (vlq_line.h); other shapes and the plain IVFPQ path compute in fp32
+    if (ivfpqConfig_.useFloat16LookupTables && subQuantizers_ == 16 && bitsPerCode_ == 8)
+      VLQ_CHECK(vlq_line_set_float16_tables(line_, 1));
     edgeInfoV_.resize((size_t)nlist_ * numedge_);
     edgeDistInfoV_.resize((size_t)nlist_ * numedge_);
     lambdaInfoV_.resize(nLambda_);
@@ -418,9 +422,11 @@ class GpuIndexIVFPQ : public GpuIndex {
   // The reference's own drivers ask for float16 look-up tables / coarse storage
   // (gpu/test/deep1b16_query.cpp:239-243: co.useFloat16 = true -> config.useFloat16LookupTables), a
   // speed/memory option of its CUDA kernels (gpu/GpuIndexIVFPQ.h:24-38, impl/IVFPQ.cu:1442 toHalf).
-  // They are ACCEPTED and recorded; this library computes the same quantities in fp32 -- every result
-  // the fp16 configuration could return is returned at higher precision, and the fp32 path is the one
-  // pinned bit for bit to the CPU index.  Only options that would change SEMANTICS are rejected.
+  // They are ACCEPTED: the VLQ search (the drivers' path) builds float16 tables the way the reference
+  // does (vlq_line_set_float16_tables); the plain IVFPQ path and the coarse quantizer compute the same
+  // quantities in fp32 -- every result the fp16 configuration could return is returned at higher
+  // precision, and fp32 is the path pinned bit for bit to the CPU index.  Only options that would
+  // change SEMANTICS are rejected.
   void verifyConfig_() const {
     FAISS_THROW_IF_NOT_MSG(ivfpqConfig_.memorySpace == MemorySpace::Device || ivfpqConfig_.memorySpace == MemorySpace::Unified,
                            "unknown memory space");

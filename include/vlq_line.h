@@ -72,6 +72,13 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
                     int64_t* I, int32_t* lines_out);
 int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
 
+/* GpuIndexIVFPQConfig::useFloat16LookupTables (gpu/GpuIndexIVFPQ.h:24-38) for the VLQ search -- what the
+ * reference's VLQ drivers run with (gpu/test/deep1b16_query.cpp:239-243).  As in the reference: term 2 and
+ * term 3 are kept as half (impl/IVFPQ.cu:1442), the per-line tables are formed in half arithmetic
+ * (impl/PQScanMultiPassPrecomputed.cu:54-75, :313-334) and the looked-up entries are summed in float.
+ * Off by default (fp32 tables); M = 16 x 8 bit only.  Halves the table bytes that bound the scan. */
+int vlq_line_set_float16_tables(vlq_line_t h, int enable);
+
 #ifdef __cplusplus
 }
 #endif

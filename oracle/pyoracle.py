@@ -53,6 +53,7 @@ def lib():
         L.orc_search.restype = C.c_int64
         L.orc_num_threads.restype = C.c_int
         L.orc_vlq_search.restype = C.c_int64
+        L.orc_vlq_search_fp16.restype = C.c_int64
         if "OMP_NUM_THREADS" not in os.environ:
             try:
                 granted = len(os.sched_getaffinity(0))
@@ -365,7 +366,8 @@ class OracleVLQ:
         np.cumsum(cnt, out=self.line_off[1:])
         return line, lb, codes
 
-    def search(self, x, nprobe, w1, k, return_lines=False):
+    def search(self, x, nprobe, w1, k, return_lines=False, fp16=False):
+        """fp16: float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, vlq_oracle.cpp)"""
         x = _f32(x).reshape(-1, self.d)
         n = x.shape[0]
         if self.term2 is None:
@@ -374,6 +376,7 @@ class OracleVLQ:
         I = np.empty((n, k), np.int64)
         lines = np.empty((n, w1), np.int32)
         s = self._c()
-        self.last_ncode = int(lib().orc_vlq_search(C.byref(s), _p(x), C.c_size_t(n), C.c_int(nprobe),
+        fn = lib().orc_vlq_search_fp16 if fp16 else lib().orc_vlq_search
+        self.last_ncode = int(fn(C.byref(s), _p(x), C.c_size_t(n), C.c_int(nprobe),
                                                    C.c_int(w1), C.c_int(k), _p(D), _p(I), _p(lines)))
         return (D, I, lines) if return_lines else (D, I)

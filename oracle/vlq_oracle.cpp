@@ -23,6 +23,8 @@
 // one-byte index into the 1-D codebook lambda_info[nlambda] and a PQ code of the
 // residual to the anchor (1-l) c_i + l s.
 // =============================================================================
+#include <immintrin.h>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -148,6 +150,19 @@ void orc_vlq_pq_encode(const orc_vlq* ix, const float* res, size_t n, uint8_t* c
         }
 }
 
+// --- float16 look-up tables (config.useFloat16LookupTables, what the reference's VLQ drivers run with:
+// gpu/test/deep1b16_query.cpp:239-243).  The reference keeps term 2 and term 3 as half
+// (impl/IVFPQ.cu:1442 toHalf; precompTerm2 / precompTerm3 are Tensor<half>), forms the two LDS tables
+// with HALF arithmetic (loadPrecomputedTerm :54-75 Math<Half8>::add, loadPrecomputedTermGraph :313-334
+// Math<Half8>::sub) and accumulates the looked-up entries in float (ConvertTo<float>::to, :798-805).
+// h16(): float -> half, round to nearest even.  hadd / hsub: IEEE half add = the float sum of the two
+// (exactly representable operands) rounded once more to half -- innocuous double rounding, because
+// float carries 24 >= 2*11 + 2 significand bits.
+static inline uint16_t h16(float x) { return (uint16_t)_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT); }
+static inline float f32h(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t hadd16(uint16_t a, uint16_t b) { return h16(f32h(a) + f32h(b)); }
+static inline uint16_t hsub16(uint16_t a, uint16_t b) { return h16(f32h(a) - f32h(b)); }
+
 struct VCand { float dis; int64_t pos; int64_t id; };
 static inline bool vless(const VCand& a, const VCand& b) { return a.dis < b.dis || (a.dis == b.dis && a.pos < b.pos); }
 
@@ -181,8 +196,21 @@ static inline bool vless(const VCand& a, const VCand& b) { return a.dis < b.dis 
 //      minimum in the lambda quantiser, lowest scan position in the final top-k (the reference's
 //      bitonic3 / BlockSelect leave ties unspecified).
 // Returns the number of codes visited.
+static int64_t vlq_search_impl(const orc_vlq* ix, const float* xq, size_t nq, int nprobe, int w1, int k,
+                               float* D, int64_t* I, int32_t* lines_out, int fp16);
+
 int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe, int w1, int k,
                        float* D, int64_t* I, int32_t* lines_out /* [nq][w1] or NULL */) {
+    return vlq_search_impl(ix, xq, nq, nprobe, w1, k, D, I, lines_out, 0);
+}
+// the same search with float16 look-up tables (see h16 above); coarse stage and line select are fp32
+int64_t orc_vlq_search_fp16(const orc_vlq* ix, const float* xq, size_t nq, int nprobe, int w1, int k,
+                            float* D, int64_t* I, int32_t* lines_out) {
+    return vlq_search_impl(ix, xq, nq, nprobe, w1, k, D, I, lines_out, 1);
+}
+
+static int64_t vlq_search_impl(const orc_vlq* ix, const float* xq, size_t nq, int nprobe, int w1, int k,
+                               float* D, int64_t* I, int32_t* lines_out, int fp16) {
     const int d = ix->d, E = ix->nedge;
     const size_t mk = (size_t)ix->M * ix->ksub;
     std::vector<float> cn(ix->nlist);
@@ -253,6 +281,12 @@ int64_t orc_vlq_search(const orc_vlq* ix, const float* xq, size_t nq, int nprobe
                     float tmp = 0.f;
                     for (int m = 0; m < ix->M; m++) {
                         const size_t idx = (size_t)m * ix->ksub + code[m];
+                        if (fp16) {
+                            const uint16_t hc = h16(t2c[idx]), hs = h16(t2s[idx]);
+                            dist += f32h(hadd16(hc, h16(t3[idx])));
+                            tmp += f32h(hsub16(hs, hc));
+                            continue;
+                        }
                         dist += t2c[idx] + t3[idx];          // term23 entry (loadPrecomputedTerm :54-75)
                         tmp += t2s[idx] - t2c[idx];          // term4 entry (loadPrecomputedTermGraph :313-334)
                     }

@@ -3,6 +3,8 @@
 // (same shapes, same drand48 stream, same acceptance bar n_ok > 0.4 * nq); part 2
 // follows the shape of gpu/test/TestGpuIndexIVFPQ.cpp (GPU index built from a CPU
 // index must answer like it -- here: identically); part 3 checks error behaviour.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -157,8 +159,10 @@ int main() {
   // part 2e: the configuration block of the reference's VLQ drivers, as they write it
   // (gpu/test/deep1b16_query.cpp:224-243; gpu/test/sift1b16_query.cpp likewise): float16 look-up
   // tables requested through GpuClonerOptions, ids "on the CPU", a temp-memory fraction.  It must
-  // construct, train, add and search -- and, because this library computes the requested fp16
-  // quantities in fp32, answer exactly like the default configuration.
+  // construct, train, add and search.  The VLQ search then runs with float16 look-up tables (as the
+  // reference does): its answers stay within the reference's own GPU-vs-CPU bar of the fp32 answers
+  // (relative distance error <= 0.015, gpu/test/TestGpuIndexIVFPQ.cpp:89-99); the plain IVFPQ index
+  // computes in fp32 whatever the flag says and answers exactly like the CPU index.
   {
     faiss::gpu::StandardGpuResources resources;
     resources.setTempMemoryFraction(0.25);
@@ -189,7 +193,21 @@ int main() {
     drv.search(nq, queries.data(), k, d16.data(), n16.data());
     base.search(nq, queries.data(), k, d32.data(), n32.data());
     EXPECT(drv.getFloat16LookupTables() && !base.getFloat16LookupTables());
-    EXPECT(n16 == n32 && d16 == d32);
+    {
+      int same = 0;
+      double worst = 0;
+      for (size_t i = 0; i < n16.size(); i++) {
+        same += n16[i] == n32[i];
+        // returned distances omit |q|^2: compare on the scale of the true distance
+        double qn = 0;
+        for (int j = 0; j < d; j++) qn += (double)queries[(i / k) * d + j] * queries[(i / k) * d + j];
+        const double rel = std::fabs((double)d16[i] - d32[i]) / std::max(1e-6, (double)d32[i] + qn);
+        if (n16[i] == n32[i] && rel > worst) worst = rel;
+      }
+      printf("part 2e: fp16 tables vs fp32: %d of %zu labels equal, max relative distance error %.2e\n", same, n16.size(), worst);
+      EXPECT(same >= (int)(0.9 * n16.size()));       // TestGpuIndexIVFPQ.cpp: <= 10 % differing results
+      EXPECT(worst <= 0.015);
+    }
     // the same options on the plain IVFPQ copy-constructor (GpuAutoTune.cpp's cloner fills them in alike)
     faiss::gpu::GpuIndexIVFPQ copy16(&resources, &index, cfg16);
     copy16.setNumProbes(5);

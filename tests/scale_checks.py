@@ -58,7 +58,7 @@ def check_ivfpq_sample(g, xs, nprobe, k, pq, coarse=None, imi=None, imi_nbits=0)
     return out
 
 
-def check_vlq_sample(g, xs, nprobe, w1, k, coarse, pq, lambda_info, edge_info, edge_dist):
+def check_vlq_sample(g, xs, nprobe, w1, k, coarse, pq, lambda_info, edge_info, edge_dist, fp16=False):
     """g: GpuVLQ holding the big index.  Lines selected for the sample queries are fetched from the
     device; the VLQ oracle then searches the same queries on that sparse copy."""
     from oracle.pyoracle import OracleVLQ
@@ -84,7 +84,7 @@ def check_vlq_sample(g, xs, nprobe, w1, k, coarse, pq, lambda_info, edge_info, e
     v.lambdas = np.ascontiguousarray(np.concatenate(lams)) if lams else v.lambdas
     v.ids = np.ascontiguousarray(np.concatenate(ids)) if ids else v.ids
     v.line_off = off
-    Do, Io, lo = v.search(xs, nprobe, w1, k, return_lines=True)
+    Do, Io, lo = v.search(xs, nprobe, w1, k, return_lines=True, fp16=fp16)
     # the oracle sees only the fetched lines: every line it selects must be one the device selected too
     out = {"queries": int(xs.shape[0]), "lines_fetched": int(uniq.shape[0]), "codes_in_fetched_lines": int(cnt.sum()),
            "lines_equal": bool(np.array_equal(lines, lo)), "distance_bits_equal": bool(np.array_equal(_bits(D), _bits(Do))),

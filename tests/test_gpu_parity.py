@@ -161,14 +161,14 @@ def test_wide_rows_two_level_select(nlist, d, nprobe):
         assert np.array_equal(bits(cd2[:, :nprobe]), bits(cd)) and np.array_equal(keys2[:, :nprobe], keys)
 
 
-@pytest.mark.parametrize("nq", [1, 3, 16, 100, 500])
+@pytest.mark.parametrize("nq", [1, 3, 16, 100, 500, 1250, 2500, 3000])     # 1250 / 2500: a 10 000-query batch over 8 / 4 GPUs
 def test_small_batches_split_scan(nq):
     """Serving-size batches: a query's probes are split over up to 8 workgroups and the partial rows
     merged -- same distances, same labels, same tie order as the unsplit scan and the oracle."""
     case = Case("c1_small")
     g = gpu_index(case)
     ox = case.oracle_index()
-    xq = np.concatenate([case.xq] * 8)[:nq]
+    xq = np.concatenate([case.xq] * (1 + nq // case.xq.shape[0]))[:nq]
     for nprobe, k in ((64, 10), (8, 1), (33, 100), (64, 256)):
         D, I = g.search(xq, nprobe, k)
         Do, Io = ox.search(xq, nprobe, k, canonical=True)

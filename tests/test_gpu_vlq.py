@@ -180,3 +180,45 @@ def test_random_vlq_configuration(seed):
     Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
     assert np.array_equal(lines, lo)
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
+# ---------------------------------------------------------------------------------------------
+# float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (16, 128, 128), (64, 300, 300), (128, 1024, 128), (200, 1024, 1000)])
+def test_fp16_tables_bit_exact_vs_fp16_oracle(world16, nprobe, w1, k):
+    """half(term 2), half(term 3), half add / subtract for the two tables, float accumulation: the
+    device must reproduce the oracle's float16 mode bit for bit (same order, same ties)."""
+    v, _, xq = world16
+    g = gpu_from_oracle(v)
+    g.set_float16_tables(True)
+    D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
+    Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True, fp16=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    g.set_float16_tables(False)                       # and back: the fp32 tables are untouched
+    D32, I32 = g.search(xq, nprobe, w1, k)
+    Do32, Io32 = v.search(xq, nprobe, w1, k)
+    assert np.array_equal(bits(D32), bits(Do32)) and np.array_equal(I32, Io32)
+
+
+def test_fp16_tables_within_the_reference_gpu_vs_cpu_bar(world16):
+    """gpu/test/TestGpuIndexIVFPQ.cpp:89-99: relative distance error <= 0.015 and <= 10 % differing
+    results between float16 tables and the fp32 answer (distances compared on the |q - y|^2 scale)."""
+    v, _, xq = world16
+    g = gpu_from_oracle(v)
+    D32, I32 = g.search(xq, 32, 256, 50)
+    g.set_float16_tables(True)
+    D16, I16 = g.search(xq, 32, 256, 50)
+    qn = (xq.astype(np.float64) ** 2).sum(1)[:, None]
+    ok = (I32 >= 0) & (I16 == I32)
+    rel = np.abs(D16.astype(np.float64) - D32)[ok] / np.maximum(D32[ok] + np.broadcast_to(qn, D32.shape)[ok], 1e-9)
+    assert rel.max() <= 0.015
+    assert (I16 == I32).mean() >= 0.9
+
+
+def test_fp16_tables_only_for_16_byte_codes(world):
+    v, _, _ = world
+    g = gpu_from_oracle(v)            # M = 8 x 6 bit
+    with pytest.raises(vlq.VlqError):
+        g.set_float16_tables(True)

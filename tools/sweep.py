@@ -14,9 +14,11 @@ print("# Search sweep, one MI355X, bench index (d=128, nlist=4096, M=16x8 bit, 1
 print("Queries and results resident in HBM; time per `search()` call = median of 7 after 2 warm-ups.\n")
 print("| batch | nprobe | k | ms per call | queries/s | codes per query |")
 print("|---|---|---|---|---|---|")
-for nq in (1, 16, 128, 1000, 10000, 100000):
+for nq in (1, 16, 128, 1000, 1250, 2500, 5000, 10000, 100000):      # 1250 / 2500 / 5000: slices of a 10 000-query batch over 8 / 4 / 2 GPUs
     for nprobe, k in ((32, 10), (8, 10), (128, 10), (32, 1), (32, 100), (32, 1000)):
         if nq == 100000 and (nprobe, k) not in ((32, 10), (8, 10)):
+            continue
+        if nq in (1250, 2500, 5000) and (nprobe, k) != (32, 10):
             continue
         xq = xq_all[:nq].contiguous()
         D = torch.empty((nq, k), dtype=torch.float32, device=dev); I = torch.empty((nq, k), dtype=torch.int64, device=dev)

@@ -3,7 +3,8 @@
 NB=1000000000): build on the device, time the search, and VERIFY it -- a sample of queries is checked
 bit for bit against the VLQ oracle on the lines it selects, fetched back from the device, and stored
 vectors used as queries must come back (tests/scale_checks.py).
-   python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D, CHECK (sample size, default 6)"""
+   python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D, CHECK (sample size, default 6),
+   FP16=1: float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -40,6 +41,9 @@ pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
 xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
 nself = min(nq, first.shape[0]) // 2
 xq[:nself] = first[:nself]                              # half the batch: stored vectors
+fp16 = bool(E("FP16", 0))
+g.set_float16_tables(fp16)
+print("look-up tables: %s" % ("float16" if fp16 else "float32"), flush=True)
 D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
 I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
 for _ in range(2):
@@ -63,7 +67,7 @@ s1, sk = scale_checks.self_hit(Ih[:nself])
 print("self-hit: %d stored vectors as queries: first %.4f, in top-%d %.4f" % (nself, s1, k, sk), flush=True)
 ns = E("CHECK", 6)
 pick = np.r_[0:ns // 2, nself:nself + ns - ns // 2]
-res = scale_checks.check_vlq_sample(g, xq[pick].cpu().numpy(), nprobe, w1, k, cent, pq, lam, ei, ed)
+res = scale_checks.check_vlq_sample(g, xq[pick].cpu().numpy(), nprobe, w1, k, cent, pq, lam, ei, ed, fp16=fp16)
 print("oracle sample check:", res, flush=True)
 assert sk >= 0.9 and res["ok"], "verification failed"
 print("VERIFIED")

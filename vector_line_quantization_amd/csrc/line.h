@@ -43,6 +43,9 @@ struct LineScanArgs {
     const int64_t* line_len = nullptr;   // [nlist*nedge] lengths, or nullptr: packed (lists.h)
     const float* term2;          // [nlist][M*ksub]
     const float* qtab;           // [nq][M*ksub]  <q_m, cent_mj>
+    // float16 look-up tables (useFloat16LookupTables, 16-byte scan only): half(term2) and half(-2 <q_m, cent_mj>)
+    const uint16_t* term2h = nullptr;    // [nlist][M*ksub]
+    const uint16_t* qtabh = nullptr;     // [nq][M*ksub]
     const int32_t* edge_info;    // [nlist*nedge]
     const float* edge_dist;      // [nlist*nedge]
     const float* lambda_info;    // [nlambda]
@@ -58,5 +61,7 @@ struct LineScanArgs {
     int w1, k, M, ksub, nedge, max_line_codes;
 };
 void launch_line_scan(const LineScanArgs& a, hipStream_t s);
+// out[i] = half(scale * in[i]) (round to nearest even); scale = 1 (term 2) or -2 (term 3, IVFPQ.cu:1409-1442)
+void launch_to_half(const float* in, int64_t n, float scale, uint16_t* out, hipStream_t s);
 
 }  // namespace vlq

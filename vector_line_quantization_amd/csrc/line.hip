@@ -499,6 +499,203 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
 }
 
 // ---------------------------------------------------------------------------
+// float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables -- what the reference's VLQ
+// drivers run with, gpu/test/deep1b16_query.cpp:239-243).  As in the reference: term 2 and term 3 are
+// kept as half (impl/IVFPQ.cu:1442), the two tables are formed with HALF arithmetic
+// (PQScanMultiPassPrecomputed.cu:54-75 add, :313-334 sub) and the looked-up entries are accumulated in
+// float (:798-805).  A line then costs one 8 KB row instead of 16 KB -- the bytes that bound this scan.
+// Same line order, same scan positions, same summation order as line16_scan_kernel.
+// ---------------------------------------------------------------------------
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+union H8 { uint4 u; h16x2 h[4]; };
+
+__global__ void to_half_kernel(const float* __restrict__ in, int64_t n, float scale, uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const _Float16 h = (_Float16)__fmul_rn(scale, in[i]);
+    out[i] = __builtin_bit_cast(uint16_t, h);
+}
+void launch_to_half(const float* in, int64_t n, float scale, uint16_t* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, scale, out);
+}
+
+// T23h at LDS byte 0, T4h at byte 8192: one SDWA op makes code byte * 2, both 16-bit reads use it
+#define VLQ_H16_BLOCK(W0, W1, O)                                                                   \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_u16 %8, %0 offset:8192+" #O "+0\n\t" \
+        "ds_read_u16 %0, %0 offset:" #O "+0\n\t" \
+        "ds_read_u16 %9, %1 offset:8192+" #O "+512\n\t" \
+        "ds_read_u16 %1, %1 offset:" #O "+512\n\t" \
+        "ds_read_u16 %10, %2 offset:8192+" #O "+1024\n\t" \
+        "ds_read_u16 %2, %2 offset:" #O "+1024\n\t" \
+        "ds_read_u16 %11, %3 offset:8192+" #O "+1536\n\t" \
+        "ds_read_u16 %3, %3 offset:" #O "+1536\n\t" \
+        "ds_read_u16 %12, %4 offset:8192+" #O "+2048\n\t" \
+        "ds_read_u16 %4, %4 offset:" #O "+2048\n\t" \
+        "ds_read_u16 %13, %5 offset:8192+" #O "+2560\n\t" \
+        "ds_read_u16 %5, %5 offset:" #O "+2560\n\t" \
+        "ds_read_u16 %14, %6 offset:8192+" #O "+3072\n\t" \
+        "ds_read_u16 %6, %6 offset:" #O "+3072\n\t" \
+        "ds_read_u16 %15, %7 offset:8192+" #O "+3584\n\t" \
+        "ds_read_u16 %7, %7 offset:" #O "+3584\n\t" \
+        "s_waitcnt lgkmcnt(0)"                                                                                 \
+        : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]), "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7])                                                                               \
+        : "v"(W0), "v"(W1), "v"(one)                                                       \
+        : "memory")
+
+template <int KPL>
+__global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(LineScanArgs a, int queue_off) {
+    constexpr int E = 4096, NT = 256, NI = 2;       // a row of 4096 halves = 512 x 16 bytes: two per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    uint4* t23 = reinterpret_cast<uint4*>(smraw);                    // [E] halves at LDS byte 0
+    uint4* t4 = reinterpret_cast<uint4*>(smraw + 8192);              // [E] halves at LDS byte 8192
+    float* lamtab = reinterpret_cast<float*>(smraw + 16384);         // [256]
+    u64* queue = reinterpret_cast<u64*>(smraw + queue_off);          // [4][64]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1] scan position of the rank-th line
+    uint16_t* wmap = reinterpret_cast<uint16_t*>(cum + a.w1 + 1);    // [w1] rank -> record index
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (__builtin_amdgcn_groupstaticsize() != 0) return;             // the table offsets above are absolute
+    uint32_t one = 1;
+    asm volatile("" : "+v"(one));
+    const int64_t q = blockIdx.x;
+    const int cnt = a.sel_cnt[q];
+    const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);   // 3 x 16 bytes per record
+
+    H8 q3[NI];                            // half(-2 <q_m, cent_mj>), entries 8*(i*256+t) .. +7
+    {
+        const uint4* qt = reinterpret_cast<const uint4*>(a.qtabh + q * E);
+#pragma unroll
+        for (int i = 0; i < NI; i++) q3[i].u = qt[i * NT + t];
+    }
+    lamtab[t] = a.lambda_info[t];         // padded to 256 entries by the host
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    H8 t2c[NI], ts[NI];
+    uint4 c0 = make_uint4(0, 0, 0, 0);
+    uint32_t l0 = 0;
+    auto prefetch = [&](const uint4 m0, const uint4 m1) __attribute__((always_inline)) {
+        const int64_t off = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+        const uint32_t len = m0.z;
+        const int32_t s = (int32_t)m1.x;
+        const uint4* src = reinterpret_cast<const uint4*>(a.term2h + (size_t)s * E);
+#pragma unroll
+        for (int i = 0; i < NI; i++) ts[i].u = src[i * NT + t];
+        const uint32_t j = min((uint32_t)t, len - 1);
+        c0 = reinterpret_cast<const uint4*>(a.codes)[off + j];
+        l0 = a.lambdas[off + j];
+    };
+    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, ma2 = ma0, mb0 = ma0, mb1 = ma0, mb2 = ma0;
+    if (cnt > 0) {
+        ma0 = mq[0]; ma1 = mq[1]; ma2 = mq[2];
+        const int w1c = min(1, cnt - 1);
+        mb0 = mq[3 * w1c]; mb1 = mq[3 * w1c + 1]; mb2 = mq[3 * w1c + 2];
+        prefetch(ma0, ma1);
+    }
+    int cprev = -1;
+    uint32_t total = 0;
+    for (int w = 0; w < cnt; w++) {
+        const int64_t off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane(ma0.y) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane(ma0.x));
+        const uint32_t len = __builtin_amdgcn_readfirstlane(ma0.z);
+        const int line = __builtin_amdgcn_readfirstlane(ma0.w);
+        const float c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.y));
+        const float b2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.z));
+        const float g = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.w));
+        const uint32_t pos0 = __builtin_amdgcn_readfirstlane(ma2.x);
+        const int rank = __builtin_amdgcn_readfirstlane(ma2.y);
+        const int c = line / a.nedge;
+        if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
+        __syncthreads();                         // previous line fully scanned
+        if (c != cprev) {                        // new anchor: its half row into registers, T23h into LDS
+            const uint4* src = reinterpret_cast<const uint4*>(a.term2h + (size_t)c * E);
+#pragma unroll
+            for (int i = 0; i < NI; i++) t2c[i].u = src[i * NT + t];
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                H8 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v.h[e] = t2c[i].h[e] + q3[i].h[e];      // half add, round to nearest even
+                t23[i * NT + t] = v.u;
+            }
+            cprev = c;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            H8 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v.h[e] = ts[i].h[e] - t2c[i].h[e];          // half subtract
+            t4[i * NT + t] = v.u;
+        }
+        uint4 cc = c0;
+        uint32_t lb = l0;
+        ma0 = mb0; ma1 = mb1; ma2 = mb2;
+        if (w + 1 < cnt) {
+            prefetch(ma0, ma1);
+            const int w2 = min(w + 2, cnt - 1);
+            mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
+        }
+        __syncthreads();
+        const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
+        const uint8_t* lp = a.lambdas + off;
+        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
+            const uint32_t j = j0 + lane;
+            const uint32_t jn = min(j + NT, len - 1);
+            const uint4 cn = cp[jn];
+            const uint32_t ln = lp[jn];
+            const float l = lamtab[lb];
+            float dist = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)), __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+            float tmp = 0.f;
+            auto h2f = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)v); };
+            {
+                uint32_t va[8], vb[8];
+                VLQ_H16_BLOCK(cc.x, cc.y, 0);
+#pragma unroll
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, h2f(va[m])); tmp = __fadd_rn(tmp, h2f(vb[m])); }
+            }
+            {
+                uint32_t va[8], vb[8];
+                VLQ_H16_BLOCK(cc.z, cc.w, 4096);
+#pragma unroll
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, h2f(va[m])); tmp = __fadd_rn(tmp, h2f(vb[m])); }
+            }
+            dist = __fadd_rn(dist, __fmul_rn(l, tmp));
+            sel.template offer<false>(dist, pos0 + j, j < len);
+            cc = cn;
+            lb = ln;
+        }
+        total += len;
+    }
+    if (t == 0) cum[cnt] = total;
+
+    ScanArgs em;                 // only the fields merge_and_emit reads
+    em.k = a.k;
+    em.nprobe = cnt > 0 ? cnt : 1;
+    em.store_pairs = 0;
+    em.ids = a.ids;
+    em.D = a.D;
+    em.I = a.I;
+    if (cnt == 0 && t == 0) cum[1] = 0;
+    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane, [&](int rank, int64_t& lkey, int64_t& loff) {
+        const uint4 m0 = mq[3 * (int)wmap[rank]];
+        lkey = (int64_t)(int32_t)m0.w;
+        loff = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+    });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)total);
+}
+
+// ---------------------------------------------------------------------------
 // line scan: one 256-thread workgroup per query walks its selected lines.  Per line
 // (c, s): two LUTs in LDS,  T23 = term2[c] + (-2 <q, cent>)  and  T4 = term2[s] - term2[c],
 // then per code (lambda l from the one-byte codebook)
@@ -609,6 +806,12 @@ static void launch_line_scan_t(const LineScanArgs& a, int lut_region, size_t sme
 }
 
 template <int KPL>
+static void launch_line16h_scan_t(const LineScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(line16h_scan_kernel<KPL>), smem);
+    hipLaunchKernelGGL((line16h_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, queue_off);
+}
+
+template <int KPL>
 static void launch_line16_scan_t(const LineScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(line16_scan_kernel<KPL>), smem);
     hipLaunchKernelGGL((line16_scan_kernel<KPL>), dim3((unsigned)a.nq), dim3(256), smem, s, a, queue_off);
@@ -616,6 +819,17 @@ static void launch_line16_scan_t(const LineScanArgs& a, int queue_off, size_t sm
 
 void launch_line_scan(const LineScanArgs& a, hipStream_t s) {
     if (a.nq <= 0) return;
+    if (a.M == 16 && a.ksub == 256 && a.sel_meta && a.term2h) {
+        // half tables: T23h, T4h (8 KB each) + lambda table; the merge area (4 x k keys) aliases them
+        size_t lutb = (size_t)2 * 4096 * 2 + 256 * 4;
+        const size_t merge = (size_t)4 * a.k * 8;
+        if (lutb < merge) lutb = merge;
+        const size_t smem16 = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + ((size_t)a.w1 + 2) * 2 + 16;
+        if (a.k <= 64) launch_line16h_scan_t<1>(a, (int)lutb, smem16, s);
+        else if (a.k <= 256) launch_line16h_scan_t<4>(a, (int)lutb, smem16, s);
+        else launch_line16h_scan_t<16>(a, (int)lutb, smem16, s);
+        return;
+    }
     if (a.M == 16 && a.ksub == 256 && a.sel_meta) {
         size_t lutb = (size_t)2 * 4096 * 4 + 256 * 4;      // T23, T4, lambda table; the merge area aliases T23/T4
         const size_t smem16 = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + ((size_t)a.w1 + 2) * 2 + 16;

@@ -12,6 +12,9 @@ struct vlq_line_s {
     int64_t nlines = 0, ntotal = 0, ntotal_added = 0;
     DevBuf edge_info, edge_dist, lambda_info, codes, lambdas, ids, line_off, line_len;   // lists.h layout
     bool have_graph = false, have_lambda = false;
+    // float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables): half(term2), built on demand
+    bool fp16_tables = false, term2h_valid = false;
+    DevBuf term2h, ws_qtabh;
     std::vector<int64_t> h_line_off, h_line_len;
     bool h_lines_stale = false;
     AppendWs ws_append;
@@ -120,7 +123,7 @@ void vlq_line_destroy(vlq_line_t h) {
                       &h->line_off, &h->line_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
                       &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_sel_meta, &h->ws_sel_cnt, &h->ws_x, &h->ws_D,
-                      &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats};
+                      &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats, &h->term2h, &h->ws_qtabh};
     for (auto b : bufs) b->release();
     if (h->base) vlq_ivfpq_destroy(h->base);
     delete h;
@@ -131,14 +134,24 @@ int vlq_line_set_stream(vlq_line_t h, void* s) {
     return vlq_ivfpq_set_stream(h->base, s);
 }
 
+int vlq_line_set_float16_tables(vlq_line_t h, int enable) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (enable && !(h->base->M == 16 && h->base->ksub == 256))
+        return fail(VLQ_ERR_UNSUPPORTED, "float16 look-up tables are built for 16 x 8-bit codes (the reference drivers' shape)");
+    h->fp16_tables = enable != 0;
+    return VLQ_OK;
+}
+
 int vlq_line_set_coarse_centroids(vlq_line_t h, const float* c) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     h->have_graph = false;
+    h->term2h_valid = false;
     return vlq_ivfpq_set_coarse_centroids(h->base, c);
 }
 
 int vlq_line_set_pq_centroids(vlq_line_t h, const float* c) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    h->term2h_valid = false;
     return vlq_ivfpq_set_pq_centroids(h->base, c);
 }
 
@@ -383,6 +396,12 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
         // compact records (16-byte scan kernel): their sort key holds the candidate index in 24 bits
         const bool with_meta = b->M == 16 && b->ksub == 256 && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
+        const bool fp16 = h->fp16_tables && with_meta;
+        if (fp16 && !h->term2h_valid) {      // half(term 2), once per trained state (impl/IVFPQ.cu:1442 toHalf)
+            TRY(h->term2h.reserve((size_t)b->nlist * E * 2));
+            vlq::launch_to_half(b->term2.as<float>(), (int64_t)b->nlist * (int64_t)E, 1.f, h->term2h.as<uint16_t>(), b->stream);
+            h->term2h_valid = true;
+        }
         vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
                                 h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
                                 sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream,
@@ -391,6 +410,10 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
         vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
                               b->ws_qtab.as<float>(), b->stream);
+        if (fp16) {                            // half(term 3) = half(-2 <q_m, cent_mj>)
+            TRY(h->ws_qtabh.reserve((size_t)pn * E * 2));
+            vlq::launch_to_half(b->ws_qtab.as<float>(), ni * (int64_t)E, -2.f, h->ws_qtabh.as<uint16_t>(), b->stream);
+        }
         // 4. scan + top-k
         vlq::LineScanArgs a;
         a.codes = h->codes.as<uint8_t>(); a.lambdas = h->lambdas.as<uint8_t>(); a.ids = h->ids.as<int64_t>();
@@ -398,6 +421,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
         a.lambda_info = h->lambda_info.as<float>();
         a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();
+        if (fp16) { a.term2h = h->term2h.as<uint16_t>(); a.qtabh = h->ws_qtabh.as<uint16_t>(); }
         a.sel_meta = with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() : nullptr; a.sel_cnt = h->ws_sel_cnt.as<int32_t>();
         a.D = (float*)Dd + i0 * k; a.I = (int64_t*)Id + i0 * k;
         a.ncode = h->stats.as<unsigned long long>();

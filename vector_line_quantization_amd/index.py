@@ -250,6 +250,10 @@ class GpuVLQ:
         p, _k = _ptr(li, np.float32)
         check(lib().vlq_line_set_lambda_codebook(self._h, p))
 
+    def set_float16_tables(self, enable=True):
+        """GpuIndexIVFPQConfig::useFloat16LookupTables for the VLQ search (include/vlq_line.h)"""
+        check(lib().vlq_line_set_float16_tables(self._h, C.c_int(int(enable))))
+
     def set_graph(self, edge_info, edge_dist):
         pe, _a = _ptr(edge_info, np.int32)
         pd, _b = _ptr(edge_dist, np.float32)
