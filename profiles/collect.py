@@ -17,15 +17,20 @@ shutil.copy(os.path.join(SRC, "sweep.md"), dst("sweep.md"))
 shutil.copy(one("imi10/**/*kernel_stats.csv"), dst("imi_kernel_stats.csv"))
 shutil.copy(one("imi14/**/*kernel_stats.csv"), dst("imi14_kernel_stats.csv"))
 shutil.copy(one("vlq/**/*kernel_stats.csv"), dst("vlq_kernel_stats.csv"))
+for extra in ("vlq_fp16.log", "sched_ab.txt", "host_buffers.txt"):
+    if os.path.exists(os.path.join(SRC, extra)):
+        shutil.copy(os.path.join(SRC, extra), dst(extra if extra.endswith(".txt") else extra.replace(".log", ".txt")))
 with open(dst("long_lists.txt"), "w") as f:
     f.write("# tools/long_lists.py: random codes straight into the lists, 10 000 queries; K / DIM / NPROBE as in profiles/refresh.sh\n")
     f.write(open(os.path.join(SRC, "long_lists.txt")).read())
     f.write("# tools/large_k.py (bench index, nprobe 32, 10 000 queries)\n")
     f.write(open(os.path.join(SRC, "large_k.txt")).read())
 with open(dst("imi_vlq.txt"), "w") as f:
-    for n in ("imi10.log", "imi14.log", "vlq4m.log", "vlq.log"):
+    for n in ("imi10.log", "imi14.log", "vlq4m.log", "vlq.log", "vlq_fp16.log"):
+        if not os.path.exists(os.path.join(SRC, n)):
+            continue
         lines = [l for l in open(os.path.join(SRC, n)).read().splitlines()
-                 if l.startswith(("added", "search")) ]
+                 if l.startswith(("added", "search", "look-up", "self-hit", "oracle sample", "VERIFIED")) ]
         f.write("# %s\n%s\n" % (n, "\n".join(lines)))
 
 # HBM traffic of the scan kernel per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts 64 B per
@@ -39,5 +44,9 @@ out = {"kernel": re.search(r"void (vlq::scan16_kernel<1[^>]*>)", txt).group(1),
        "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request of wide coalesced reads, MI355X_MICROARCH.md §HBM)",
        "hbm_bytes_per_launch": (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024,
        "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])}
+# bench.py reports this figure only while the scan-kernel sources are the ones that were profiled
+sys.path.insert(0, os.path.dirname(HERE))
+import bench
+out["sources_sha256"] = bench.sources_sha()
 json.dump(out, open(dst("scan_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

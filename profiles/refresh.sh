@@ -1,17 +1,21 @@
 #!/bin/bash
-# Regenerates the inputs of the committed profiles on the GPU box (one gpurun call, from the repo
-# root):  bash profiles/refresh.sh r01   -> gpurun_out/r01/...   then copy the summaries into
-# profiles/ (profiles/collect.py r01).  Counter passes run without tracing domains.
+# Regenerates the inputs of the committed profiles on the GPU box (two gpurun calls, from the repo
+# root):  bash profiles/refresh.sh r02 a   (bench, kernel trace, PMC passes)
+#         bash profiles/refresh.sh r02 b   (sweeps, multi-index / VLQ / long-list / schedule runs)
+# -> gpurun_out/r02/...   then copy the summaries into profiles/ (python profiles/collect.py r02).
+# Counter passes run without tracing domains.
 set -e
-R=${1:-r01}
+R=${1:-r02}
+PART=${2:-ab}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 REPO=$GRAFT_REPO_ROOT
 T="timeout -k 10"
+if [[ $PART == *a* ]]; then
 $T 400 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done" >&2
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline --no-second-dataset > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline --no-second-dataset --no-host-buffers > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done" >&2
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc --no-second-dataset) > $OUT/pmc.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
@@ -19,12 +23,16 @@ python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc2 --no-second-dataset --sigma 0.005 --rank 12 --spread 0.4) > $OUT/pmc2.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc2 > $OUT/pmc2_summary.txt
 echo "pmc done" >&2
+fi
+if [[ $PART == *b* ]]; then
 $T 300 python $REPO/tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
 echo "sweep done" >&2
 NBITS=10 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/imi10 -- python $REPO/tools/time_imi.py > $OUT/imi10.log 2>&1
 NBITS=14 NB=20000000 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/imi14 -- python $REPO/tools/time_imi.py > $OUT/imi14.log 2>&1
 NB=16000000 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vlq -- python $REPO/tools/time_vlq.py > $OUT/vlq.log 2>&1
 NB=4000000 $T 300 python $REPO/tools/time_vlq.py > $OUT/vlq4m.log 2>&1
+FP16=1 NB=16000000 $T 300 python $REPO/tools/time_vlq.py > $OUT/vlq_fp16.log 2>&1
+$T 300 python $REPO/tools/sched_ab.py 20 2>/dev/null | grep -v "amdgpu\|^\[bench\]" > $OUT/sched_ab.txt
 echo "imi/vlq done" >&2
 {
   for K in 10 100 256 1000; do K=$K $T 200 python $REPO/tools/long_lists.py 64000000 16384 10000 2>/dev/null | grep -v amdgpu; done
@@ -32,4 +40,5 @@ echo "imi/vlq done" >&2
   NPROBE=64 K=10 $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu
 } > $OUT/long_lists.txt
 $T 200 python $REPO/tools/large_k.py 2>/dev/null | grep total > $OUT/large_k.txt
+fi
 echo "all done" >&2
