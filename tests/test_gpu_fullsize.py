@@ -70,8 +70,8 @@ def test_full_batch_vs_compiled_reference(world, tmp_path):
 
 
 def test_host_buffers_device_buffers_and_schedules_agree(world):
-    """The same 10 000 queries through the paged host-buffer path (numpy in / out: three pages, copies
-    overlapped with the search), through device buffers, and under the list-owned schedule: one answer."""
+    """The same 10 000 queries through host buffers (numpy in / out), through device buffers, and under
+    the list-owned schedule: one answer."""
     import torch
     g, xq = world["g"], world["xq"]
     xd = torch.from_numpy(xq).cuda()

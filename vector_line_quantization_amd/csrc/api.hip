@@ -478,7 +478,6 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi};
     for (auto b : bufs) b->release();
-    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -761,82 +760,20 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
     return VLQ_OK;
 }
 
-// Host buffers, large batch (the reference drivers' calling convention; GpuIndex::search pages such
-// calls too, gpu/GpuIndex.cu:108-147): the batch is cut into a short first page and growing later
-// pages; the pageable H2D copy of page i+1 (copy stream; the call blocks the HOST while the GPU keeps
-// running) lands while page i is searched, and page i's results leave while page i+1 is searched.
-// Exposed on the critical path: the first page's copy-in and the last page's copy-out.
-static int search_host_paged(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k, float* D, int64_t* I) {
-    if (!h->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    TRY(h->ws_x.reserve((size_t)n * h->d * 4));
-    TRY(h->ws_D.reserve((size_t)n * k * 4));
-    TRY(h->ws_I.reserve((size_t)n * k * 8));
-    TRY(h->ws_keys.reserve((size_t)n * nprobe * 8));
-    TRY(h->ws_cdis.reserve((size_t)n * nprobe * 4));
-    int64_t start[8], count[8];
-    int np = 0;
-    {   // 10 % / 30 % / 60 %: a page's search covers the next page's copy
-        const int64_t cuts[3] = {std::max<int64_t>(512, n / 10), std::max<int64_t>(1024, (n * 3) / 10), n};
-        int64_t at = 0;
-        for (int i = 0; i < 3 && at < n; i++) {
-            const int64_t c = (i == 2) ? n - at : std::min(cuts[i], n - at);
-            start[np] = at; count[np] = c; at += c; np++;
-        }
-    }
-    std::vector<hipEvent_t> ev_in((size_t)np), ev_done((size_t)np);
-    for (int i = 0; i < np; i++) { ev_in[(size_t)i] = get_event(h); ev_done[(size_t)i] = get_event(h); if (!ev_in[(size_t)i] || !ev_done[(size_t)i]) return fail(VLQ_ERR_HIP, "hipEventCreate failed"); }
-    float* xd = h->ws_x.as<float>();
-    float* Dd = h->ws_D.as<float>();
-    int64_t* Id = h->ws_I.as<int64_t>();
-    // what the caller queued on the index's stream comes first
-    hipEvent_t ev0 = get_event(h);
-    HIP_TRY(hipEventRecord(ev0, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->copy_stream, ev0, 0));
-    int rc = VLQ_OK;
-    for (int i = 0; i < np && rc == VLQ_OK; i++) {
-        const int64_t s0 = start[i], c = count[i];
-        hipError_t e = hipMemcpyAsync(xd + s0 * h->d, x + s0 * h->d, (size_t)c * h->d * 4, hipMemcpyHostToDevice, h->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(ev_in[(size_t)i], h->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev_in[(size_t)i], 0);
-        if (e != hipSuccess) { rc = fail(VLQ_ERR_HIP, "host-buffer paging: %s", hipGetErrorString(e)); break; }
-        rc = coarse_dev(h, c, xd + s0 * h->d, nprobe, h->ws_cdis.as<float>() + s0 * nprobe, h->ws_keys.as<int64_t>() + s0 * nprobe);
-        if (rc == VLQ_OK)
-            rc = scan_dev(h, c, xd + s0 * h->d, h->ws_keys.as<int64_t>() + s0 * nprobe, h->ws_cdis.as<float>() + s0 * nprobe,
-                          nprobe, k, Dd + s0 * k, Id + s0 * k, 0);
-        if (rc != VLQ_OK) break;
-        e = hipEventRecord(ev_done[(size_t)i], h->stream);
-        if (e != hipSuccess) { rc = fail(VLQ_ERR_HIP, "host-buffer paging: %s", hipGetErrorString(e)); break; }
-        if (i > 0) {     // results of the previous page leave while this page is searched
-            const int64_t p0 = start[i - 1], pc = count[i - 1];
-            e = hipStreamWaitEvent(h->copy_stream, ev_done[(size_t)i - 1], 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(D + p0 * k, Dd + p0 * k, (size_t)pc * k * 4, hipMemcpyDeviceToHost, h->copy_stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(I + p0 * k, Id + p0 * k, (size_t)pc * k * 8, hipMemcpyDeviceToHost, h->copy_stream);
-            if (e != hipSuccess) { rc = fail(VLQ_ERR_HIP, "host-buffer paging: %s", hipGetErrorString(e)); break; }
-        }
-    }
-    if (rc == VLQ_OK) {
-        const int64_t p0 = start[np - 1], pc = count[np - 1];
-        hipError_t e = hipStreamWaitEvent(h->copy_stream, ev_done[(size_t)np - 1], 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(D + p0 * k, Dd + p0 * k, (size_t)pc * k * 4, hipMemcpyDeviceToHost, h->copy_stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(I + p0 * k, Id + p0 * k, (size_t)pc * k * 8, hipMemcpyDeviceToHost, h->copy_stream);
-        if (e != hipSuccess) rc = fail(VLQ_ERR_HIP, "host-buffer paging: %s", hipGetErrorString(e));
-    }
-    (void)hipStreamSynchronize(h->copy_stream);
-    (void)hipStreamSynchronize(h->stream);
-    for (auto e : ev_in) h->ev_pool.push_back(e);
-    for (auto e : ev_done) h->ev_pool.push_back(e);
-    h->ev_pool.push_back(ev0);
-    return rc;
-}
-
+// Host buffers (the reference drivers' calling convention): copy in, search, copy out on the index's
+// stream.  Two overlapped variants were built and measured on the bench batch (10 000 queries, pageable
+// numpy buffers, tools/host_buffers.py) and LOST to this plain sequence (1.09 ms = 1.25x the
+// device-resident step): three pages of 10/30/60 % with the copies of one page beside the search of
+// another 1.21 ms (1.39x: three small searches cost more than the 0.11 + 0.04 ms of copies they hide);
+// chunked copy-in with the coarse stage chunk by chunk behind it and ONE scan 1.13 ms (1.32x).  A
+// pageable hipMemcpyAsync blocks the host, so nothing can be enqueued behind it without pinning the
+// caller's pages; DESIGN.md section 7.
 int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k, float* D,
                      int64_t* I) {
     TRY(check_ready(h, true));
     TRY(check_search_args(h, n, x, nprobe, k, D, I));
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
-    if (n >= 4096 && !is_device_ptr(x) && !is_device_ptr(D) && !is_device_ptr(I))
-        return search_host_paged(h, n, x, nprobe, k, D, I);
     const void* xd;
     TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     TRY(h->ws_keys.reserve((size_t)n * nprobe * 8));

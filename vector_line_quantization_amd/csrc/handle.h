@@ -84,7 +84,6 @@ struct vlq_ivfpq_s {
     int64_t max_codes = 0;
     int64_t ntotal = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // host-buffer searches: H2D / D2H of one page beside the search of another
 
     // inverted lists: list i at [list_off[i], list_off[i] + list_len[i]), capacity list_off[i+1] - list_off[i]
     DevBuf coarse, cnorm, pq, pq_t, rnorm, term2, codes, ids, list_off, list_len;
