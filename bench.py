@@ -78,8 +78,10 @@ def kmeans(torch, x, k, niter, gen):
     return cent
 
 
-def build_index(args, dev, xt=None, xb=None):
-    """xt / xb given: real vectors (.fvecs); otherwise generator G1 of SURVEY.md section 8(d)."""
+def build_index(args, dev, xt=None, xb=None, bcast=None):
+    """xt / xb given: real vectors (.fvecs); otherwise generator G1 of SURVEY.md section 8(d).
+    bcast(t): N > 1 -- the quantizers are trained on rank 0 and broadcast, so that every rank holds the SAME
+    index (the k-means below accumulates with float atomics: two GPUs would not train bit-equal centroids)."""
     import torch
     import vector_line_quantization_amd as vlq
     d, nlist, M, nbits = args.d, args.nlist, args.M, 8
@@ -93,15 +95,21 @@ def build_index(args, dev, xt=None, xb=None):
         gen.manual_seed(22)
         xb = gmm(torch, gen, centres, args.nb, args.sigma, dev, args.rank, args.spread)
     t0 = time.time()
-    gen.manual_seed(1234)
-    coarse = kmeans(torch, xt, nlist, 10, gen)
-    # residual PQ training set (IndexIVFPQ.cpp:73-104): subsample to 256*ksub points
-    ntr = min(args.nt, 256 * ksub)
-    xs = xt[torch.randperm(args.nt, generator=gen, device=dev)[:ntr]]
-    a = ((coarse * coarse).sum(1)[None, :] - 2.0 * xs @ coarse.T).argmin(1)
-    res = xs - coarse[a]
-    pq = torch.stack([kmeans(torch, res[:, m * dsub:(m + 1) * dsub].contiguous(), ksub, 25, gen)
-                      for m in range(M)])
+    if bcast is None or int(os.environ.get("RANK", "0")) == 0:
+        gen.manual_seed(1234)
+        coarse = kmeans(torch, xt, nlist, 10, gen)
+        # residual PQ training set (IndexIVFPQ.cpp:73-104): subsample to 256*ksub points
+        ntr = min(xt.shape[0], 256 * ksub)
+        xs = xt[torch.randperm(xt.shape[0], generator=gen, device=dev)[:ntr]]
+        a = ((coarse * coarse).sum(1)[None, :] - 2.0 * xs @ coarse.T).argmin(1)
+        res = xs - coarse[a]
+        pq = torch.stack([kmeans(torch, res[:, m * dsub:(m + 1) * dsub].contiguous(), ksub, 25, gen)
+                          for m in range(M)])
+    else:
+        coarse = torch.empty((nlist, d), dtype=torch.float32, device=dev)
+        pq = torch.empty((M, ksub, dsub), dtype=torch.float32, device=dev)
+    if bcast is not None:
+        coarse, pq = bcast(coarse.contiguous()), bcast(pq.contiguous())
     torch.cuda.synchronize()
     log("trained coarse+PQ in %.1fs" % (time.time() - t0))
 
@@ -110,10 +118,10 @@ def build_index(args, dev, xt=None, xb=None):
     g.set_coarse_centroids(coarse.contiguous())
     g.set_pq_centroids(pq.contiguous())
     t0 = time.time()
-    for i0 in range(0, args.nb, 262144):          # device-side encode + append
+    for i0 in range(0, xb.shape[0], 262144):          # device-side encode + append
         g.add(xb[i0:i0 + 262144].contiguous())
     torch.cuda.synchronize()
-    log("added %d vectors in %.1fs (HIP encode path)" % (args.nb, time.time() - t0))
+    log("added %d vectors in %.1fs (HIP encode path)" % (xb.shape[0], time.time() - t0))
     return g, centres, coarse, pq, xb
 
 
@@ -341,6 +349,10 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
+    def _bcast(t):
+        dist.broadcast(t, src=0)
+        return t
+    bcast = _bcast if (use_dist and not stub) else None
     fdir = None if stub else find_fvecs_dir(args.fvecs_dir)
     gt = None
     if stub:
@@ -352,11 +364,11 @@ def main():
         gpath = os.path.join(fdir, "groundtruth.ivecs")
         if os.path.exists(gpath):
             gt = fvecs_read(gpath).view(np.int32)[:, 0].astype(np.int64)
-        g, centres, coarse, pq, xb = build_index(args, dev, xt=torch.from_numpy(xt_h).to(dev), xb=torch.from_numpy(xb_h).to(dev))
+        g, centres, coarse, pq, xb = build_index(args, dev, xt=torch.from_numpy(xt_h).to(dev), xb=torch.from_numpy(xb_h).to(dev), bcast=bcast)
         default_workload = False
         lens, imb = list_stats(g, args.nlist)
     else:
-        g, centres, coarse, pq, xb = build_index(args, dev)
+        g, centres, coarse, pq, xb = build_index(args, dev, bcast=bcast)
         lens, imb = list_stats(g, args.nlist)
 
     def queries(seed, n):
