@@ -337,19 +337,13 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             else {
                 // fewer workgroups than the chip holds (256 CUs x 4): split every query's probes over
                 // several workgroups and join the partial rows -- serving-size batches
-                // (also mid-size batches whose workgroups would fill the 1024 slots of the chip a fractional
-                // number of times -- 1250 queries = 2 rounds with the second one 22 % full: split in 4 it is
-                // 5 rounds of quarter-length workgroups = 1.25 -- the slices of a batch sharded over 4 or 8 GPUs)
+                // (mid-size batches -- 1250 / 2500 queries, the slices of a batch sharded over 8 / 4 GPUs, which
+                // fill the 1024 slots a fractional number of times -- were tried with 2-8 parts too: a workgroup
+                // costs about 19 us of slot time before and after its probes against 1.5 us per probe, so the
+                // finer granularity buys nothing: 625 queries 0.090 -> 0.123 ms split in 8, 1250 queries 0.16 ms
+                // either way; tools/slice_stages.py)
                 int nsplit = 1;
-                if (k <= 256) {
-                    auto rounds = [&](int sp) { return (double)((ni * sp + 1023) / 1024) / sp * (1.0 + 0.03 * (sp > 1) + 0.01 * sp); };
-                    double best = rounds(1);
-                    for (int sp = 2; sp <= 8; sp *= 2) {
-                        if (nprobe / sp < 4) break;
-                        const double c = rounds(sp);
-                        if (c < best * 0.97) { best = c; nsplit = sp; }
-                    }
-                }
+                while (k <= 256 && nsplit < 8 && ni * nsplit * 2 <= 1024 && nprobe / (nsplit * 2) >= 4) nsplit *= 2;
                 if (nsplit > 1) {
                     TRY(h->ws_Dp.reserve((size_t)nsplit * ni * k * sizeof(float)));
                     TRY(h->ws_Ip.reserve((size_t)nsplit * ni * k * sizeof(int64_t)));
