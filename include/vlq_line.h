@@ -76,7 +76,10 @@ int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
  * reference's VLQ drivers run with (gpu/test/deep1b16_query.cpp:239-243).  As in the reference: term 2 and
  * term 3 are kept as half (impl/IVFPQ.cu:1442), the per-line tables are formed in half arithmetic
  * (impl/PQScanMultiPassPrecomputed.cu:54-75, :313-334) and the looked-up entries are summed in float.
- * Off by default (fp32 tables); M = 16 x 8 bit only.  Halves the table bytes that bound the scan. */
+ * Off by default (fp32 tables); M = 16 x 8 bit only.  Halves the table bytes that bound the scan.
+ * As in the reference, the table entries must fit the half range (|value| <= 65504): fine for
+ * normalised descriptors (Deep1B, the drivers' data), NOT for raw byte-valued vectors such as SIFT,
+ * whose term 2 entries reach 10^5 and become infinite. */
 int vlq_line_set_float16_tables(vlq_line_t h, int enable);
 
 #ifdef __cplusplus
