@@ -8,9 +8,12 @@
 //     64-lane network (scan16_kernel<16>: 4.7 ms per 10 000 queries at k = 1000, nearly all of it
 //     merges); one shared list admits k (1 + ln(n / k)) and 256 threads merge it;
 //   * admitted keys (ordered distance << 32 | scan position: a total order, so the result does
-//     not depend on which wave met a code) are appended to a shared LDS queue; the workgroup
-//     walks a list in trips of 256 codes with one barrier per trip, and when the queue may not
-//     take another trip it is sorted (bitonic, in LDS) and merged into the sorted best list;
+//     not depend on which wave met a code) are appended to a shared LDS queue behind the current
+//     best keys; the workgroup walks a list in trips of 256 codes with one barrier per trip, and
+//     when the queue may not take another trip the k smallest of (best + queue) are kept: the
+//     k-th smallest key is found by an MSB-first radix select (8-bit digits, LDS histogram, stops
+//     as soon as one candidate is left), the keepers of the queue move into the holes the losers
+//     leave in the best area -- no sort; the best keys are sorted once, at the end;
 //   * positions do not arrive in increasing order across waves, so candidates whose distance
 //     EQUALS the current k-th distance are queued too and the full key decides (WaveSelect's
 //     unordered rule); FLT_MAX itself is never admitted.
@@ -70,13 +73,13 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
     constexpr int E = 4096, NT = 256, NI = 4, NW = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [2][E] at LDS offsets 0 / 16384
-    u64* best = reinterpret_cast<u64*>(smraw + lut_region);               // [KC] sorted ascending
-    u64* pend = best + KC;                                                // [kPendCap]
+    u64* best = reinterpret_cast<u64*>(smraw + lut_region);               // [KC] the best keys so far (unsorted until the end)
+    u64* pend = best + KC;                                                // [kPendCap] queue, contiguous behind them
     ProbeMeta pm;
     pm.carve(reinterpret_cast<unsigned char*>(pend + kPendCap), a.nprobe);
     int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(pend + kPendCap) +
-                                               ProbeMeta::bytes(a.nprobe));    // cut, nlive, npend, thr bits, [2][4] per-wave trip counts
-    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 12);                     // [nprobe] visited probes
+                                               ProbeMeta::bytes(a.nprobe));    // cut, nlive, npend, thr bits, [2][4] trip counts, select state
+    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 20);                     // [nprobe] visited probes
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (__builtin_amdgcn_groupstaticsize() != 0) { *a.bad_key = 2; return; }
@@ -112,22 +115,99 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
     const int nlive = misc[1];
     float thr = 3.402823466e+38f;          // distance of the k-th best key so far, or FLT_MAX
 
-    // merge the pending keys into the best list; every thread of the workgroup calls it
+    // keep the k smallest keys of best[0..KC) + pend[0..n); every thread of the workgroup calls it.
+    // misc[12] = digit chosen, misc[13] = rank still wanted inside it, misc[14] = candidates left,
+    // misc[15..16] = the k-th key, misc[17] / misc[18] = hole / mover counts
+    // Scratch of a flush (digit counts, hole and mover lists: 5 KB) lives in the LUT buffer that is NOT in
+    // use: while probe i is scanned from buffer `buf`, the other buffer's table (probe i-1) is consumed and
+    // the next one is built only after this probe's last trip.
+    int buf = 0;
     auto flush = [&]() {
+        unsigned char* scratch = reinterpret_cast<unsigned char*>(lut + (buf ^ 1) * E);
+        int32_t* hist = reinterpret_cast<int32_t*>(scratch);                  // [256] radix-select digit counts
+        uint16_t* holes = reinterpret_cast<uint16_t*>(hist + 256);            // [KC] slots of the best area that lose their key
+        uint16_t* movers = holes + KC;                                        // [kPendCap] queue entries that stay
         const int n = misc[2];
+        const int N = KC + n;                      // entries of the contiguous array best | pend
+        u64* all = best;
+        u64 prefix = 0;                            // digits decided so far (high bytes)
+        int want = a.k;                            // 1-based rank of the wanted key among the candidates
+        int shift = 56;
+        bool unique = false;
         __syncthreads();
-        for (int e = n + t; e < kPendCap; e += NT) pend[e] = kMaxKey;
+        for (; shift >= 0; shift -= 8) {
+            hist[t] = 0;
+            __syncthreads();
+            const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+            // (the leading bytes of ordered distances are nearly constant: 64 lanes adding to ONE counter would
+            // serialise in the LDS atomic unit, so a wave whose candidates all share the digit adds once)
+            for (int e0 = 0; e0 < N; e0 += NT) {
+                const int e = e0 + t;
+                int digit = -1;
+                if (e < N) {
+                    const u64 key = all[e];
+                    if ((key & himask) == prefix) digit = (int)((key >> shift) & 255u);
+                }
+                const u64 part = __ballot(digit >= 0);
+                if (part != 0) {
+                    const int src = __builtin_ffsll((long long)part) - 1;
+                    const int d0 = __shfl(digit, src, 64);
+                    const u64 same = __ballot(digit == d0);
+                    if (same == part) { if (lane == src) atomicAdd(&hist[d0], __popcll(part)); }
+                    else if (digit >= 0) atomicAdd(&hist[digit], 1);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {                       // the digit whose cumulative count reaches `want`
+                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+                const int own = c0 + c1 + c2 + c3;
+                int incl = own;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    const int o = __shfl_up(incl, sft, 64);
+                    if (lane >= sft) incl += o;
+                }
+                const int before = incl - own;
+                if (before < want && want <= incl) {   // exactly one lane
+                    int r = want - before, d = 0, cnt = c0;
+                    if (r > c0) { r -= c0; d = 1; cnt = c1; if (r > c1) { r -= c1; d = 2; cnt = c2; if (r > c2) { r -= c2; d = 3; cnt = c3; } } }
+                    misc[12] = 4 * lane + d;
+                    misc[13] = r;
+                    misc[14] = cnt;
+                }
+            }
+            __syncthreads();
+            prefix |= (u64)(uint32_t)misc[12] << shift;
+            want = misc[13];
+            if (misc[14] == 1) { unique = true; break; }     // one candidate left: fetch it instead of more passes
+        }
+        u64 kth = prefix;
+        if (unique && shift > 0) {
+            const u64 himask = ~0ull << shift;
+            for (int e = t; e < N; e += NT) {
+                const u64 key = all[e];
+                if ((key & himask) == prefix) { misc[15] = (int32_t)(uint32_t)key; misc[16] = (int32_t)(uint32_t)(key >> 32); }
+            }
+            __syncthreads();
+            kth = ((u64)(uint32_t)misc[16] << 32) | (uint32_t)misc[15];
+        }
+        // keepers: real keys <= kth (exactly k of them unless fewer than k real keys exist: then kth
+        // is the padding value and every real key stays).  Queue keepers move into the holes of the
+        // best area.
+        if (t == 0) { misc[17] = 0; misc[18] = 0; }
         __syncthreads();
-        wg_bitonic_sort<kPendCap>(pend, t);
-        // the KC smallest of best U pend: element-wise minimum against the reversed head of pend
-        // leaves a bitonic sequence holding exactly those keys
         for (int e = t; e < KC; e += NT) {
-            const u64 x = best[e], y = pend[KC - 1 - e];
-            best[e] = x < y ? x : y;
+            const u64 key = all[e];
+            if (!(key <= kth && key != kMaxKey)) holes[atomicAdd(&misc[17], 1)] = (uint16_t)e;
+        }
+        for (int e = t; e < n; e += NT) {
+            const u64 key = pend[e];
+            if (key <= kth && key != kMaxKey) movers[atomicAdd(&misc[18], 1)] = (uint16_t)e;
         }
         __syncthreads();
-        wg_bitonic_merge<KC>(best, t);
-        const u64 kth = best[a.k - 1];
+        const int nholes = misc[17], nmov = misc[18];
+        for (int e = t; e < nholes; e += NT) best[holes[e]] = e < nmov ? pend[movers[e]] : kMaxKey;
+        __syncthreads();
         if (t == 0) {
             misc[2] = 0;
             misc[3] = (int32_t)(kth == kMaxKey ? __float_as_uint(3.402823466e+38f)
@@ -169,7 +249,6 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
         c0 = (reinterpret_cast<const uint4*>(a.codes) + n_off)[min((uint32_t)t, n_len - 1)];
     };
     prefetch(0);
-    int buf = 0;
     uint64_t nscan = 0;
     // Queue fill as every thread knows it.  The slot of a key comes from an LDS atomic on misc[2], but the
     // decision to flush must be the same in all four waves, and a wave that is already in the next trip
@@ -211,7 +290,8 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
         nscan += len;
         buf ^= 1;
     }
-    flush();                                                  // (also publishes the final list to every thread)
+    flush();
+    wg_bitonic_sort<KC>(best, t);                             // the one sort: rows leave in ascending key order
     // rows out
     for (int e = t; e < a.k; e += NT) {
         const u64 key = best[e];
@@ -248,7 +328,7 @@ void launch_scan16_bigk(const ScanArgs& a_in, hipStream_t s) {
     a.xcd_chunk = (int)((a.nq + 7) / 8);
     const int kc = a.k <= 512 ? 512 : 1024;
     const size_t lutb = (size_t)2 * 4096 * 4;
-    const size_t smem = lutb + (size_t)(kc + kPendCap) * 8 + (size_t)a.nprobe * 24 + 8 + 48 + (size_t)a.nprobe * 2 + 64;
+    const size_t smem = lutb + (size_t)(kc + kPendCap) * 8 + (size_t)a.nprobe * 24 + 8 + 80 + (size_t)a.nprobe * 2 + 64;
     const bool imi = a.imi_nbits > 0;
     if (kc == 512) { if (imi) launch_bigk_t<512, true>(a, (int)lutb, smem, s); else launch_bigk_t<512, false>(a, (int)lutb, smem, s); }
     else { if (imi) launch_bigk_t<1024, true>(a, (int)lutb, smem, s); else launch_bigk_t<1024, false>(a, (int)lutb, smem, s); }
