@@ -56,6 +56,7 @@ def test_gpu_shell_builds_against_reference_headers():
     subprocess.check_call(["make", "-s", "-C", CPP, "link_against_reference"])
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "oracle/_ref/mkl") + ":" + env.get("LD_LIBRARY_PATH", "")
+    env["OMP_NUM_THREADS"] = "8"
     p = subprocess.run(["./link_against_reference"], cwd=CPP, env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "reference CPU index: ntotal=2000 use_precomputed_table=1" in p.stdout
@@ -71,6 +72,10 @@ def test_gpu_shell_with_reference_library_on_gpu():
         pytest.skip("link_against_reference was not prebuilt (needs the reference tree at build time)")
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "oracle/_ref/mkl") + ":" + env.get("LD_LIBRARY_PATH", "")
+    # the reference's OpenMP loops would start one spinning thread per logical CPU of the host (256 on the
+    # GPU boxes, 16 granted): 200 s instead of 2
+    env["OMP_NUM_THREADS"] = "8"
+    env["OMP_WAIT_POLICY"] = "passive"
     p = subprocess.run([exe, "gpu"], cwd=CPP, env=env, capture_output=True, text=True, timeout=600)
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
