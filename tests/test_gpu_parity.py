@@ -445,3 +445,28 @@ def test_nearest_centroid_without_distance_matrix(nlist, d):
     assert np.array_equal(keys3[:, :1], keys) and np.array_equal(bits(cd3[:, :1]), bits(cd))
     assign, _codes = g.encode(xq)
     assert np.array_equal(assign, keys[:, 0])
+
+
+@pytest.mark.parametrize("k", [300, 1000])
+def test_multi_index_with_workgroup_selection(k):
+    """Inverted multi-index + table type 2 through the one-selection-per-workgroup kernel (k > 256,
+    scan16_bigk_kernel<.., IMI>): lists long enough for the per-probe table kernel, ties from duplicated
+    vectors, against the oracle."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(k)
+    nbits, d, M = 3, 128, 16
+    kc, dc = 1 << nbits, d // 2
+    imi = rng.random((2, kc, dc), dtype=np.float32)
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.4).astype(np.float32)
+    xb = rng.random((6000, d), dtype=np.float32)
+    xb[3000:3400] = xb[100:500]                       # exact duplicates: equal distances
+    xq = rng.random((150, d), dtype=np.float32)
+    ox = OracleIndex(d, kc * kc, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits)
+    ox.add(xb, canonical=True)
+    g = vlq.GpuIVFPQ(d, kc * kc, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    g.set_lists(ox.codes, ox.ids, ox.list_offsets)
+    D, I = g.search(xq, 16, k)
+    Do, Io = ox.search(xq, 16, k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)

@@ -331,7 +331,12 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             if (variant && variant[0] == '2') vlq::launch_scan16v2(a, h->stream);
             else if (variant && variant[0] == 'p' && a.qorder && vlq::scan16p_supports(a)) vlq::launch_scan16p(a, h->stream);
             else if (variant && variant[0] == 'w') vlq::launch_scan16w(a, variant[1] == '2' ? 2 : variant[1] == '1' ? 1 : 4, h->stream);
-            else
+            else if (variant && variant[0] == 's' && k <= 64 && h->imi_nbits == 0 && ni >= 1024) {
+                // persistent "stream" kernel (experiments/scan16s.hip): s = overlapped, s0 = serial
+                if (h->ws_own_count.reserve(64) != VLQ_OK) return VLQ_ERR_HIP;
+                a.own_next = h->ws_own_count.as<int>();
+                vlq::launch_scan16_stream(a, h->stream, variant[1] == '0' ? 0 : 1);
+            } else
 #endif
             if (h->ntotal < (int64_t)h->nlist * 24) vlq::launch_scan16_short(a, h->stream);   // a few codes per list
             else {

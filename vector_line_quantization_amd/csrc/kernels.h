@@ -76,6 +76,7 @@ struct ScanArgs {
     const uint8_t* list_part = nullptr;      // [nlist] partition 0..7 of every list
     const int* own_order = nullptr;          // [8][nq] the queries with probes in partition x, scheduling order
     const int* own_count = nullptr;          // [8]
+    int* own_next = nullptr;                 // [8] per-XCD work-queue heads of the stream kernel (scan16s.hip)
     unsigned long long* part_keys = nullptr; // [nq][8][k]
     const uint8_t* part_mask = nullptr;      // [nq] bit x: the query has a probe in partition x
     int qtab_scaled = 0;                     // qtab already holds (-2) * <q_m, cent_mj>
@@ -93,6 +94,9 @@ inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
 void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
 void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
 void launch_owned_merge(const ScanArgs& a, hipStream_t s);
+// same shape, k <= 64: persistent workgroups that overlap a query's set-up and merge with the probes of
+// its neighbours (scan16s.hip); a.own_next = 8 ints of device scratch (zeroed by the launcher)
+void launch_scan16_stream(const ScanArgs& a, hipStream_t s, int overlap);
 // same shape, 256 < k <= 1024: one selection per workgroup instead of one per wave (scan16k.hip)
 void launch_scan16_bigk(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
