@@ -114,8 +114,40 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
     TRY(h->ws_qn.reserve((size_t)n * sizeof(float)));
     // 1-NN (assignment): per-tile (distance, column) keys instead of the [n][nlist] matrix
     const bool argmin = nprobe == 1 && !direct && !keep_matrix && vlq::coarse_argmin_ok(h->nlist, h->d);
-    if (!argmin) TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
     float* tmin = nullptr;
+    int fs = 0, fcap = 0;
+    const bool filtered = !direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_filter &&
+                          vlq::coarse_filter_ok(h->nlist, h->d, nprobe, n, &fs, &fcap);
+    if (!argmin && !filtered) TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
+    if (filtered) {
+        // filtered coarse stage: no [n][nlist] matrix.  (1) exact distances to a sample of the column tiles
+        // and their nprobe smallest -> the nprobe-th is an upper bound of the row's nprobe-th smallest overall;
+        // (2) the full pass keeps only elements at or below the bound; (3) exact select over the kept keys.
+        const int ns = h->nlist / fs;
+        if (h->coarse_s_stride != fs) {
+            TRY(h->coarse_s.reserve((size_t)ns * h->d * sizeof(float)));
+            TRY(h->cnorm_s.reserve((size_t)ns * sizeof(float)));
+            vlq::launch_sample_tiles(h->coarse.as<float>(), h->cnorm.as<float>(), h->nlist, h->d, fs, h->coarse_s.as<float>(),
+                                     h->cnorm_s.as<float>(), h->stream);
+            h->coarse_s_stride = fs;
+        }
+        TRY(h->ws_dist.reserve((size_t)n * ns * sizeof(float)));
+        const size_t ntl = (size_t)h->nlist / 64;
+        TRY(h->ws_cand.reserve((size_t)n * ntl * fcap * 8));
+        TRY(h->ws_cnt.reserve((size_t)n * ntl));
+        vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
+        vlq::launch_coarse_distances(x_dev, h->coarse_s.as<float>(), h->ws_qn.as<float>(), h->cnorm_s.as<float>(),
+                                     h->ws_dist.as<float>(), n, ns, h->d, h->stream, nullptr);
+        vlq::launch_coarse_select(h->ws_dist.as<float>(), n, ns, nprobe, cdis_dev, keys_dev, h->stream, nullptr);
+        vlq::launch_coarse_distances_filtered(x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(), h->cnorm.as<float>(), n,
+                                              h->nlist, h->d, cdis_dev + (nprobe - 1), nprobe,
+                                              h->ws_cand.as<unsigned long long>(), h->ws_cnt.as<unsigned char>(), h->stream);
+        vlq::launch_coarse_select_cand(h->ws_cand.as<unsigned long long>(), h->ws_cnt.as<unsigned char>(), n, nprobe, cdis_dev,
+                                       keys_dev, x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(), h->cnorm.as<float>(),
+                                       h->nlist, h->d, h->stream);
+        HIP_TRY(hipGetLastError());
+        return VLQ_OK;
+    }
     if (direct) {
         vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
                                             h->nlist, h->d, h->stream);
@@ -447,6 +479,7 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
     if (const char* e = getenv("VLQ_SCAN_SCHEDULE")) h->scan_schedule = atoi(e);   // tests / experiments: 1 query-major, 2 list-owned
+    if (const char* e = getenv("VLQ_COARSE_FILTER")) h->coarse_filter = atoi(e);   // 1: filtered coarse stage (A/B; slower)
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
     int rc = h->stats.reserve(16);
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
@@ -471,7 +504,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->list_len, &h->list_rank, &h->list_part, &h->ws_own_hist, &h->ws_own_minr, &h->ws_own_order,
-                      &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
@@ -580,6 +613,7 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     h->have_coarse = true;
     h->imi_nbits = 0;
     h->term2_valid = false;
+    h->coarse_s_stride = 0;          // the sampled tiles belong to the old centroids
     return VLQ_OK;
 }
 

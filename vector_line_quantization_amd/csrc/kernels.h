@@ -26,6 +26,18 @@ bool coarse_tile_minima_ok(int nlist, int d, int nprobe);
 bool coarse_argmin_ok(int nlist, int d);
 void launch_coarse_argmin(const void* tile_keys, int64_t nq, int nlist, float* cdis, int64_t* keys, hipStream_t s);
 
+// filtered coarse stage (no distance matrix; kernels.hip): a sample of the column tiles (stride s) gives every
+// row an exact upper bound of its nprobe-th smallest distance, the full pass keeps only the elements at or
+// below it as (distance, column) keys, the select runs over those (rows whose buffer overflowed are redone)
+bool coarse_filter_ok(int nlist, int d, int nprobe, int64_t nq, int* stride_out, int* cap_out);
+void launch_sample_tiles(const float* c, const float* cn, int nlist, int d, int s, float* cs, float* cns, hipStream_t st);
+void launch_coarse_distances_filtered(const float* q, const float* c, const float* qn, const float* cn, int64_t nq, int nlist,
+                                      int d, const float* bound, int64_t bound_stride, unsigned long long* cand,
+                                      unsigned char* cnt, hipStream_t s);
+void launch_coarse_select_cand(const unsigned long long* cand, const unsigned char* cnt, int64_t nq, int nprobe, float* cdis,
+                               int64_t* keys, const float* q, const float* c, const float* qn, const float* cn, int nlist, int d,
+                               hipStream_t s);
+
 // < 20 queries: direct fvec_L2sqr per pair (utils.cpp:757-786)
 void launch_coarse_distances_direct(const float* q, const float* c, float* out, int64_t nq,
                                     int nlist, int d, hipStream_t s);

@@ -174,11 +174,26 @@ __global__ __launch_bounds__(256) void coarse_dist_kernel(
 // TMIN == 3 (1-NN: the assignment of add / encode): NO matrix; per (row, tile) one 64-bit key
 // ordered(distance) << 32 | column of the tile's (distance, column) minimum -- the total order of
 // wave_topk.cuh -- so the nearest centroid of a row is the minimum of its nlist / 64 keys.
+// TMIN == 5 (round 2, the filtered coarse stage): NO matrix either.  Every row comes with an upper bound
+// of its nprobe-th smallest distance (the nprobe-th smallest over a SAMPLE of the columns, computed
+// exactly by a first, small pass); an element at or below the bound is appended to the row's candidate
+// list as a (distance, column) key, everything else is dropped.  The candidates (a few per cent of the
+// row) are a superset of the row's nprobe nearest, so the exact select over them returns what the select
+// over the full row returns.
+constexpr int kFilterSlots = 16;     // kept keys per (row, 64-column tile); more -> the row is redone exactly
+struct CoarseFilter {
+    const float* bound;          // bound of row i = bound[i * stride]
+    int64_t stride;
+    unsigned long long* cand;    // [nq][ntiles][kFilterSlots] keys
+    unsigned char* cnt;          // [nq][ntiles] keys kept in the tile (255: overflow)
+    int ntiles;
+};
+
 template <int NU, bool VEC, int TMIN>   // k range padded to 8*NU; VEC: d % 4 == 0 (16-byte row loads)
 __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     const float* __restrict__ Q, const float* __restrict__ Cn, const float* __restrict__ qn,
     const float* __restrict__ cn, float* __restrict__ out, int64_t nq, int nlist, int d,
-    int tiles_per_block, float* __restrict__ tmin) {
+    int tiles_per_block, float* __restrict__ tmin, CoarseFilter flt) {
     constexpr int KS = 4 * NU;        // k-pair steps
     constexpr int S = KS + 4;         // padded row stride (floats) of a parity plane
     extern __shared__ __attribute__((aligned(16))) float sm[];   // 2 buffers x [2 parity][64][S]
@@ -234,10 +249,12 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         for (int u = 0; u < NU; u++) areg[u] = *reinterpret_cast<const float4*>(src + 4 * u);
     }
     float qnr[16];
+    float bnd[TMIN == 5 ? 16 : 1];
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
         const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         qnr[reg] = qn[row < nq ? row : nq - 1];
+        if (TMIN == 5) bnd[reg] = flt.bound[(row < nq ? row : nq - 1) * flt.stride];
     }
     __syncthreads();
 
@@ -304,6 +321,33 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         const bool full = (tile * 64 + 64 <= nlist) && ((nlist & 3) == 0);
         float mrow[4];
         u64 krow[4];
+        if (TMIN == 5) {
+            // lane (r, h) holds columns tile*64 + tj*32 + r of rows 8g + 4h + i (reg = 4g + i): for every row the
+            // 32 lanes of a half-wave hold 32 of its columns.  Elements at or below the row's bound are compacted
+            // into the (row, tile) slot group with a ballot -- no atomics, no matrix.
+            const uint32_t lt = (1u << r) - 1u;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                int base = 0;
+#pragma unroll
+                for (int tj = 0; tj < 2; tj++) {
+                    const int col = tile * 64 + tj * 32 + r;
+                    const float cnv = cn[col < nlist ? col : nlist - 1];
+                    const float x = __fsub_rn(__fadd_rn(qnr[reg], cnv), __fmul_rn(2.f, acc[tj][reg]));
+                    const bool pass = row < nq && col < nlist && x <= bnd[TMIN == 5 ? reg : 0] && x < FLT_MAX_F;
+                    const u64 m64 = __ballot(pass);
+                    const uint32_t mh = h ? (uint32_t)(m64 >> 32) : (uint32_t)m64;
+                    const int sl = base + __popc(mh & lt);
+                    if (pass && sl < kFilterSlots)
+                        flt.cand[((size_t)row * flt.ntiles + tile) * kFilterSlots + sl] = make_key(x, (uint32_t)col);
+                    base += __popc(mh);
+                }
+                if (r == 0 && row < nq) flt.cnt[(size_t)row * flt.ntiles + tile] = (unsigned char)(base > kFilterSlots ? 255 : base);
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
             const int col = tile * 64 + tj * 32 + r;
@@ -400,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
 
 template <int NU, bool VEC, int TMIN>
 static void launch_coarse_areg_t(const float* q, const float* c, const float* qn, const float* cn,
-                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
+                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s,
+                               CoarseFilter flt = CoarseFilter{nullptr, 0, nullptr, nullptr, 0}) {
     constexpr int S = 4 * NU + 4;
     const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN == 1 ? (size_t)4 * 32 * 17 * sizeof(float) : 0);
     ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC, TMIN>), smem);
@@ -418,7 +463,7 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
     }
     dim3 grid((unsigned)rb, (unsigned)((ntiles + best_t - 1) / best_t));
     hipLaunchKernelGGL((coarse_dist_areg_kernel<NU, VEC, TMIN>), grid, dim3(256), smem, s, q, c, qn, cn, out,
-                       nq, nlist, d, best_t, tmin);
+                       nq, nlist, d, best_t, tmin, flt);
 }
 
 template <int NU>
@@ -439,6 +484,128 @@ bool coarse_tile_minima_ok(int nlist, int d, int nprobe) {
 // 1-NN without a distance matrix (out == nullptr, tmin = [nq][nlist / 64] 64-bit keys)
 bool coarse_argmin_ok(int nlist, int d) {
     return d <= 128 && d >= 4 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256;
+}
+
+// ---------------------------------------------------------------------------
+// filtered coarse stage (round 2): sample pass -> per-row bound -> full pass that keeps only the
+// elements at or below the bound -> exact select over the kept keys.  Exact: the bound is the
+// nprobe-th smallest distance over a subset of the row's own elements, so at least nprobe elements
+// lie at or below it and every one of the row's nprobe nearest is among the kept.  A row whose kept
+// elements do not fit its candidate buffer (long runs of equal distances) is redone from scratch by
+// the select kernel: the inner products as k-ascending fmaf chains, bit-identical to the MFMA
+// accumulation.
+// ---------------------------------------------------------------------------
+bool coarse_filter_ok(int nlist, int d, int nprobe, int64_t nq, int* stride_out, int* cap_out) {
+    if (!(d <= 128 && d >= 4 && d % 4 == 0 && nlist % 64 == 0 && nprobe >= 2 && nprobe <= 256 && nq >= 256)) return false;
+    int s = 1;
+    while (s * 2 <= 16 && (int64_t)nlist / (s * 2) >= (int64_t)16 * nprobe && (nlist / 64) % (s * 2) == 0) s *= 2;
+    if (s < 4) return false;
+    *stride_out = s;
+    *cap_out = kFilterSlots;
+    return true;
+}
+
+// the sampled columns: tiles 0, s, 2s, ... of the centroid matrix, packed
+__global__ void sample_tiles_kernel(const float* __restrict__ c, const float* __restrict__ cn, int nlist, int d, int s,
+                                    float* __restrict__ cs, float* __restrict__ cns) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = nlist / s;
+    if (e >= (int64_t)ns * d) return;
+    const int64_t j = e / d;                 // sampled column
+    const int k = (int)(e % d);
+    const int64_t src = (j / 64) * 64 * s + (j % 64);
+    cs[e] = c[src * d + k];
+    if (k == 0) cns[j] = cn[src];
+}
+void launch_sample_tiles(const float* c, const float* cn, int nlist, int d, int s, float* cs, float* cns, hipStream_t st) {
+    const int64_t tot = (int64_t)(nlist / s) * d;
+    hipLaunchKernelGGL(sample_tiles_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c, cn, nlist, d, s, cs, cns);
+}
+
+void launch_coarse_distances_filtered(const float* q, const float* c, const float* qn, const float* cn, int64_t nq, int nlist,
+                                      int d, const float* bound, int64_t bound_stride, unsigned long long* cand,
+                                      unsigned char* cnt, hipStream_t s) {
+    CoarseFilter f{bound, bound_stride, cand, cnt, nlist / 64};
+    if (d <= 32) launch_coarse_areg_t<4, true, 5>(q, c, qn, cn, nullptr, nq, nlist, d, nullptr, s, f);
+    else if (d <= 64) launch_coarse_areg_t<8, true, 5>(q, c, qn, cn, nullptr, nq, nlist, d, nullptr, s, f);
+    else if (d <= 96) launch_coarse_areg_t<12, true, 5>(q, c, qn, cn, nullptr, nq, nlist, d, nullptr, s, f);
+    else launch_coarse_areg_t<16, true, 5>(q, c, qn, cn, nullptr, nq, nlist, d, nullptr, s, f);
+}
+
+// exact select over a row's kept keys; a row with an overflowed tile is recomputed in full
+template <int KPL>
+__global__ __launch_bounds__(256) void coarse_select_cand_kernel(const u64* __restrict__ cand, const unsigned char* __restrict__ cnt,
+                                                                 int ntiles, int64_t nq, int nprobe, float* __restrict__ cdis,
+                                                                 int64_t* __restrict__ keys, const float* __restrict__ Q,
+                                                                 const float* __restrict__ Cn, const float* __restrict__ qn,
+                                                                 const float* __restrict__ cn, int nlist, int d) {
+    __shared__ u64 queue[4][64];
+    __shared__ float qrow[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;   // whole wave; no workgroup barrier below
+    WaveSelect<KPL> sel;
+    sel.init(nprobe, queue[wave], lane);
+    const unsigned char* crow = cnt + q * ntiles;
+    bool ovf = false;
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {            // a lane per tile
+        const int tl = t0 + lane;
+        const int c = tl < ntiles ? (int)crow[tl] : 0;
+        ovf = ovf || __ballot(c == 255) != 0;
+    }
+    if (!ovf) {
+        for (int t0 = 0; t0 < ntiles; t0 += 64) {
+            const int tl = t0 + lane;
+            const int c = tl < ntiles ? (int)crow[tl] : 0;
+            int cmax = c;
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) cmax = max(cmax, __shfl_xor(cmax, sft, 64));
+            const u64* grp = cand + ((size_t)q * ntiles + (tl < ntiles ? tl : 0)) * kFilterSlots;
+            for (int j = 0; j < cmax; j++) {
+                const bool valid = j < c;
+                const u64 key = valid ? grp[j] : kMaxKey;
+                // columns do not arrive in increasing order: equal distances are queued, the key decides
+                sel.template offer<false>(ordered_to_f32((uint32_t)(key >> 32)), (uint32_t)key, valid);
+            }
+        }
+    } else {
+        // the whole row again, one column per lane: ip = fmaf chain over k = 0, 1, 2, ... (what the MFMA
+        // accumulates), value = (|q|^2 + |c|^2) - 2 ip (utils.cpp:884)
+        for (int k = lane; k < d; k += 64) qrow[wave][k] = Q[q * d + k];
+        __builtin_amdgcn_wave_barrier();
+        const float qnv = qn[q];
+        for (int j0 = 0; j0 < nlist; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < nlist;
+            const float* cj = Cn + (size_t)(valid ? j : 0) * d;
+            float ip = 0.f;
+            for (int k = 0; k < d; k++) ip = __fmaf_rn(qrow[wave][k], cj[k], ip);
+            const float v = __fsub_rn(__fadd_rn(qnv, cn[valid ? j : 0]), __fmul_rn(2.f, ip));
+            sel.offer(v, (uint32_t)j, valid);          // ascending columns: the ordered rule is exact
+        }
+    }
+    sel.flush();
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < nprobe) {
+            const u64 key = sel.best[r];
+            const bool miss = key == kMaxKey;
+            cdis[q * nprobe + e] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+            keys[q * nprobe + e] = miss ? -1 : (int64_t)(uint32_t)key;
+        }
+    }
+}
+
+void launch_coarse_select_cand(const unsigned long long* cand, const unsigned char* cnt, int64_t nq, int nprobe, float* cdis,
+                               int64_t* keys, const float* q, const float* c, const float* qn, const float* cn, int nlist, int d,
+                               hipStream_t s) {
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    const u64* cd = reinterpret_cast<const u64*>(cand);
+    const int ntiles = nlist / 64;
+    if (nprobe <= 64) hipLaunchKernelGGL(coarse_select_cand_kernel<1>, grid, block, 0, s, cd, cnt, ntiles, nq, nprobe, cdis, keys, q, c, qn, cn, nlist, d);
+    else hipLaunchKernelGGL(coarse_select_cand_kernel<4>, grid, block, 0, s, cd, cnt, ntiles, nq, nprobe, cdis, keys, q, c, qn, cn, nlist, d);
 }
 
 // nearest centroid of every row from the per-tile keys of the TMIN == 3 distance kernel
