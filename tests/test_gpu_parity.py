@@ -470,3 +470,27 @@ def test_multi_index_with_workgroup_selection(k):
     D, I = g.search(xq, 16, k)
     Do, Io = ox.search(xq, 16, k, canonical=True)
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
+@pytest.mark.parametrize("nlist,d,nprobe", [(4096, 128, 32), (8192, 64, 16), (16384, 96, 64)])
+def test_filtered_coarse_stage_is_exact(monkeypatch, nlist, d, nprobe):
+    """The matrix-free coarse stage (VLQ_COARSE_FILTER=1: sampled bound, filtered GEMM epilogue, select
+    over the kept keys; off by default because it is slower) returns the oracle's keys and distances bit
+    for bit -- including rows whose tiles overflow their 16-key groups (a run of 40 duplicated centroids
+    next to some queries) and are redone as fmaf chains."""
+    from oracle.pyoracle import OracleIndex
+    monkeypatch.setenv("VLQ_COARSE_FILTER", "1")
+    rng = np.random.default_rng(nlist + nprobe)
+    coarse = rng.random((nlist, d), dtype=np.float32)
+    coarse[200:240] = coarse[7]                       # 40 equal columns inside one tile: more than a group holds
+    pq = rng.random((4, 256, d // 4), dtype=np.float32)
+    xq = rng.random((600, d), dtype=np.float32)
+    xq[:20] = coarse[7] + 0.001 * rng.standard_normal((20, d)).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, 4, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, 4, 8, coarse, pq)
+    cd, keys = g.coarse_search(xq, nprobe)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(keys, keyso)
+    assert np.array_equal(bits(cd), bits(cdo))
