@@ -222,3 +222,15 @@ def test_fp16_tables_only_for_16_byte_codes(world):
     g = gpu_from_oracle(v)            # M = 8 x 6 bit
     with pytest.raises(vlq.VlqError):
         g.set_float16_tables(True)
+
+
+def test_config4_literal_shape_m32_4bit():
+    """BASELINE.json configs[4] as written: 32 sub-quantizers x 4 bits, nprobe 256, recall@100 (k = 100) --
+    served by the generic line scan (one byte per sub-quantizer index, as the reference stores codes)."""
+    v, xb, xq = make_vlq(seed=44, d=96, nlist=300, M=32, nbits=4, nedge=6, nlambda=64, nb=12000)
+    g = gpu_from_oracle(v)
+    D, I, lines = g.search(xq, 256, 1024, 100, return_lines=True)
+    Do, Io, lo = v.search(xq, 256, 1024, 100, return_lines=True)
+    assert np.array_equal(lines, lo)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    assert g.stats(reset=True) == v.last_ncode
