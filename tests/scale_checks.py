@@ -78,7 +78,7 @@ def check_vlq_sample(g, xs, nprobe, w1, k, coarse, pq, lambda_info, edge_info, e
         ids.append(i)
         cnt[line] = i.shape[0]
     np.cumsum(cnt, out=off[1:])
-    v = OracleVLQ(g.d, g.nlist, g.M, 8, g.nedge, g.nlambda, coarse, pq_centroids=pq, edge_info=edge_info,
+    v = OracleVLQ(g.d, g.nlist, g.M, g.nbits, g.nedge, g.nlambda, coarse, pq_centroids=pq, edge_info=edge_info,
                   edge_dist=edge_dist, lambda_info=lambda_info)
     v.codes = np.ascontiguousarray(np.concatenate(codes)) if codes else v.codes
     v.lambdas = np.ascontiguousarray(np.concatenate(lams)) if lams else v.lambdas

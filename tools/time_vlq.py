@@ -14,17 +14,17 @@ import vector_line_quantization_amd as vlq
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 E = lambda k, v: int(os.environ.get(k, v))
-d, nlist, nedge, M = E("D", 96), E("NLIST", 4096), E("NEDGE", 16), 16
+d, nlist, nedge, M, nbits = E("D", 96), E("NLIST", 4096), E("NEDGE", 16), E("M", 16), E("NBITS", 8)
 nb, nprobe, w1, k = E("NB", 4000000), E("NPROBE", 64), E("W1", 1024), E("K", 128)
 rng = np.random.default_rng(0)
-g = vlq.GpuVLQ(d, nlist, M, 8, nedge, 256)
+g = vlq.GpuVLQ(d, nlist, M, nbits, nedge, 256)
 g.set_stream(torch.cuda.current_stream().cuda_stream)   # the library must run in order with torch's generators
 cent = rng.random((nlist, d), dtype=np.float32)
 g.set_coarse_centroids(cent)
 ei, ed = g.build_graph()
 lam = np.linspace(-0.2, 1.2, 256).astype(np.float32)
 g.set_lambda_codebook(lam)
-pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+pq = ((rng.random((M, 1 << nbits, d // M), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
 g.set_pq_centroids(pq)
 t0 = time.time()
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
@@ -42,7 +42,7 @@ xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="
 nself = min(nq, first.shape[0]) // 2
 xq[:nself] = first[:nself]                              # half the batch: stored vectors
 fp16 = bool(E("FP16", 0))
-g.set_float16_tables(fp16)
+if fp16 or (M == 16 and nbits == 8): g.set_float16_tables(fp16)
 print("look-up tables: %s" % ("float16" if fp16 else "float32"), flush=True)
 D = torch.empty((nq, k), dtype=torch.float32, device="cuda")
 I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
@@ -56,8 +56,8 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
 ncode = g.stats() / reps
-print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s (17 B/code)" % (
-    dt * 1e3, nq, nq / dt, ncode / nq, ncode * 17 / dt / 1e9))
+print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s (code + lambda bytes)" % (
+    dt * 1e3, nq, nq / dt, ncode / nq, ncode * (M + 1) / dt / 1e9))
 
 # ---- verification (outside every timed region) ----
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -696,6 +696,176 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(Lin
 }
 
 // ---------------------------------------------------------------------------
+// line scan for SMALL tables (M * ksub <= 2048 entries, M a multiple of 4: e.g. BASELINE configs[4] as
+// written, 32 sub-quantizers x 4 bits = 512 entries): same arithmetic, same line order, same scan
+// positions as the kernels above and below, organised like line16_scan_kernel -- compact line records
+// grouped by anchor, the anchor's term2 row in registers, T23 rebuilt only when the anchor changes, and
+// the next line's far-end row, first codes and lambda bytes requested before the current line is
+// scanned.  With 512-entry tables a line costs two 2 KB rows; lines hold a handful of codes, so the
+// generic kernel's per-line chain of dependent loads was what it spent its time on.
+// EP = table entries per thread (E = 256 * EP).
+// ---------------------------------------------------------------------------
+template <int KPL, int EP>
+__global__ __launch_bounds__(256) void lineS_scan_kernel(LineScanArgs a, int queue_off) {
+    constexpr int NT = 256, E = NT * EP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* t23 = reinterpret_cast<float*>(smraw);                    // [E]
+    float* t4 = t23 + E;                                             // [E]
+    float* lamtab = t4 + E;                                          // [256]
+    u64* queue = reinterpret_cast<u64*>(smraw + queue_off);          // [4][64]
+    uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1] scan position of the rank-th line
+    uint16_t* wmap = reinterpret_cast<uint16_t*>(cum + a.w1 + 1);    // [w1] rank -> record index
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t q = blockIdx.x;
+    const int cnt = a.sel_cnt[q];
+    const int Eact = a.M * a.ksub;                                   // <= E; entries beyond it are never read
+    const int MW = a.M >> 2;                                         // 32-bit words per code
+    const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);   // 3 x 16 bytes per record
+
+    float m2q[EP];                        // -2 <q_m, cent_mj>, entries t, t + 256, ...
+#pragma unroll
+    for (int i = 0; i < EP; i++) {
+        const int e = i * NT + t;
+        m2q[i] = e < Eact ? __fmul_rn(-2.f, a.qtab[q * Eact + e]) : 0.f;
+    }
+    lamtab[t] = a.lambda_info[t];         // padded to 256 entries by the host
+    WaveSelect<KPL> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    float t2c[EP], ts[EP];
+    uint32_t cw[8];                       // this lane's first code of the next line (M <= 32 bytes)
+    uint32_t l0 = 0;
+    auto load_code = [&](int64_t row, uint32_t (&w)[8]) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(a.codes + row * a.M);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = i < MW ? p[i] : 0u;
+    };
+    auto prefetch = [&](const uint4 m0, const uint4 m1) __attribute__((always_inline)) {
+        const int64_t off = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+        const uint32_t len = m0.z;
+        const int32_t s = (int32_t)m1.x;
+        const float* src = a.term2 + (size_t)s * Eact;
+#pragma unroll
+        for (int i = 0; i < EP; i++) { const int e = i * NT + t; ts[i] = e < Eact ? src[e] : 0.f; }
+        const uint32_t j = min((uint32_t)lane + 64u * wave, len - 1);
+        load_code(off + j, cw);
+        l0 = a.lambdas[off + j];
+    };
+    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, ma2 = ma0, mb0 = ma0, mb1 = ma0, mb2 = ma0;
+    if (cnt > 0) {
+        ma0 = mq[0]; ma1 = mq[1]; ma2 = mq[2];
+        const int w1c = min(1, cnt - 1);
+        mb0 = mq[3 * w1c]; mb1 = mq[3 * w1c + 1]; mb2 = mq[3 * w1c + 2];
+        prefetch(ma0, ma1);
+    }
+    int cprev = -1;
+    uint32_t total = 0;
+    for (int w = 0; w < cnt; w++) {
+        const int64_t off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane(ma0.y) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane(ma0.x));
+        const uint32_t len = __builtin_amdgcn_readfirstlane(ma0.z);
+        const int line = __builtin_amdgcn_readfirstlane(ma0.w);
+        const float c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.y));
+        const float b2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.z));
+        const float g = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.w));
+        const uint32_t pos0 = __builtin_amdgcn_readfirstlane(ma2.x);
+        const int rank = __builtin_amdgcn_readfirstlane(ma2.y);
+        const int c = line / a.nedge;
+        if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
+        __syncthreads();                         // previous line fully scanned
+        if (c != cprev) {                        // new anchor: its row into registers, T23 into LDS
+            const float* src = a.term2 + (size_t)c * Eact;
+#pragma unroll
+            for (int i = 0; i < EP; i++) {
+                const int e = i * NT + t;
+                t2c[i] = e < Eact ? src[e] : 0.f;
+                t23[e] = __fadd_rn(t2c[i], m2q[i]);
+            }
+            cprev = c;
+        }
+#pragma unroll
+        for (int i = 0; i < EP; i++) t4[i * NT + t] = __fsub_rn(ts[i], t2c[i]);
+        uint32_t cc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cc[i] = cw[i];
+        uint32_t lb = l0;
+        ma0 = mb0; ma1 = mb1; ma2 = mb2;
+        if (w + 1 < cnt) {
+            prefetch(ma0, ma1);
+            const int w2 = min(w + 2, cnt - 1);
+            mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
+        }
+        __syncthreads();
+        for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
+            const uint32_t j = j0 + lane;
+            const bool valid = j < len;
+            uint32_t cn[8];
+            const uint32_t jn = min(j + NT, len - 1);
+            if (j0 + NT < len) load_code(off + jn, cn);       // (wave-uniform) most lines fit one trip
+            const uint32_t ln = j0 + NT < len ? a.lambdas[off + jn] : 0u;
+            const float l = lamtab[lb];
+            // PQScanMultiPassPrecomputed.cu:783-811 as written (see line16_scan_kernel)
+            float dist = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)), __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
+            float tmp = 0.f;
+            const float* p23 = t23;
+            const float* p4 = t4;
+#pragma unroll
+            for (int wd = 0; wd < 8; wd++) {
+                if (wd < MW) {
+                    const uint32_t word = cc[wd];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t code = (word >> (8 * b)) & 255u;
+                        dist = __fadd_rn(dist, p23[code]);
+                        tmp = __fadd_rn(tmp, p4[code]);
+                        p23 += a.ksub;
+                        p4 += a.ksub;
+                    }
+                }
+            }
+            dist = __fadd_rn(dist, __fmul_rn(l, tmp));
+            sel.template offer<false>(dist, pos0 + j, valid);
+            if (j0 + NT < len) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) cc[i] = cn[i];
+                lb = ln;
+            }
+        }
+        total += len;
+    }
+    if (t == 0) cum[cnt] = total;
+
+    ScanArgs em;                 // only the fields merge_and_emit reads
+    em.k = a.k;
+    em.nprobe = cnt > 0 ? cnt : 1;
+    em.store_pairs = 0;
+    em.ids = a.ids;
+    em.D = a.D;
+    em.I = a.I;
+    if (cnt == 0 && t == 0) cum[1] = 0;
+    merge_and_emit<KPL>(sel, smraw, cum, em, q, wave, lane, [&](int rank, int64_t& lkey, int64_t& loff) {
+        const uint4 m0 = mq[3 * (int)wmap[rank]];
+        lkey = (int64_t)(int32_t)m0.w;
+        loff = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
+    });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)total);
+}
+
+template <int KPL, int EP>
+static void launch_lineS_scan_t(const LineScanArgs& a, int queue_off, size_t smem, hipStream_t s) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(lineS_scan_kernel<KPL, EP>), smem);
+    hipLaunchKernelGGL((lineS_scan_kernel<KPL, EP>), dim3((unsigned)a.nq), dim3(256), smem, s, a, queue_off);
+}
+template <int KPL>
+static void launch_lineS_scan_e(const LineScanArgs& a, int ep, int queue_off, size_t smem, hipStream_t s) {
+    if (ep <= 2) launch_lineS_scan_t<KPL, 2>(a, queue_off, smem, s);
+    else if (ep <= 4) launch_lineS_scan_t<KPL, 4>(a, queue_off, smem, s);
+    else launch_lineS_scan_t<KPL, 8>(a, queue_off, smem, s);
+}
+
+// ---------------------------------------------------------------------------
 // line scan: one 256-thread workgroup per query walks its selected lines.  Per line
 // (c, s): two LUTs in LDS,  T23 = term2[c] + (-2 <q, cent>)  and  T4 = term2[s] - term2[c],
 // then per code (lambda l from the one-byte codebook)
@@ -836,6 +1006,19 @@ void launch_line_scan(const LineScanArgs& a, hipStream_t s) {
         if (a.k <= 64) launch_line16_scan_t<1>(a, (int)lutb, smem16, s);
         else if (a.k <= 256) launch_line16_scan_t<4>(a, (int)lutb, smem16, s);
         else launch_line16_scan_t<16>(a, (int)lutb, smem16, s);
+        return;
+    }
+    if (a.sel_meta && (a.M & 3) == 0 && a.M <= 32 && a.M * a.ksub <= 2048) {
+        // small tables: line records + prefetch (lineS_scan_kernel)
+        const int ep = (a.M * a.ksub + 255) / 256 <= 2 ? 2 : ((a.M * a.ksub + 255) / 256 <= 4 ? 4 : 8);
+        size_t lutb = (size_t)2 * 256 * ep * 4 + 256 * 4;
+        const size_t merge = (size_t)4 * a.k * 8;
+        if (lutb < merge) lutb = merge;
+        lutb = (lutb + 15) & ~(size_t)15;
+        const size_t smemS = lutb + 4 * 64 * 8 + ((size_t)a.w1 + 2) * 4 + ((size_t)a.w1 + 2) * 2 + 16;
+        if (a.k <= 64) launch_lineS_scan_e<1>(a, ep, (int)lutb, smemS, s);
+        else if (a.k <= 256) launch_lineS_scan_e<4>(a, ep, (int)lutb, smemS, s);
+        else launch_lineS_scan_e<16>(a, ep, (int)lutb, smemS, s);
         return;
     }
     size_t lutb = (size_t)2 * a.M * a.ksub * 4;

@@ -395,8 +395,9 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
         int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
         // compact records (16-byte scan kernel): their sort key holds the candidate index in 24 bits
-        const bool with_meta = b->M == 16 && b->ksub == 256 && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
-        const bool fp16 = h->fp16_tables && with_meta;
+        const bool small_tables = (b->M & 3) == 0 && b->M <= 32 && b->M * b->ksub <= 2048;
+        const bool with_meta = ((b->M == 16 && b->ksub == 256) || small_tables) && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
+        const bool fp16 = h->fp16_tables && with_meta && b->M == 16 && b->ksub == 256;
         if (fp16 && !h->term2h_valid) {      // half(term 2), once per trained state (impl/IVFPQ.cu:1442 toHalf)
             TRY(h->term2h.reserve((size_t)b->nlist * E * 2));
             vlq::launch_to_half(b->term2.as<float>(), (int64_t)b->nlist * (int64_t)E, 1.f, h->term2h.as<uint16_t>(), b->stream);
