@@ -624,6 +624,47 @@ __global__ __launch_bounds__(256) void qorder_place_kernel(const int64_t* __rest
     qorder[pre[bin] + atomicAdd(&cnt[bin], 1)] = (int)q;
 }
 
+// One workgroup does the whole counting sort in LDS when the batch is small (<= 2048 queries: the slices of a
+// batch sharded over several GPUs): bin counts, their exclusive prefix and the placement -- one launch
+// instead of a memset and two kernels: 15 -> 8 us at 1250 queries.  (At 10 000 queries one workgroup is too
+// serial: 33 us against 17.)
+__global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __restrict__ keys, int nq, int nprobe, int nlist,
+                                                             int* __restrict__ qorder, const int* __restrict__ list_rank,
+                                                             int shift, int nbins) {
+    extern __shared__ int cnt[];                 // [nbins] counts, then running offsets
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int b = t; b < nbins; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    auto bin_of = [&](int q) {
+        const int64_t k0 = keys[(int64_t)q * nprobe];
+        const bool ok = k0 >= 0 && k0 < nlist;
+        return ok ? ((list_rank ? list_rank[k0] : (int)k0) >> shift) : nbins - 1;
+    };
+    for (int q = t; q < nq; q += 1024) atomicAdd(&cnt[bin_of(q)], 1);
+    __syncthreads();
+    // exclusive prefix: a thread owns `per` consecutive bins
+    const int per = (nbins + 1023) / 1024;
+    const int b0 = t * per;
+    int sum = 0;
+    for (int i = 0; i < per; i++) if (b0 + i < nbins) sum += cnt[b0 + i];
+    int incl = sum;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int o = __shfl_up(incl, sft, 64);
+        if (lane >= sft) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wsum[w];
+    int run = wbase + incl - sum;
+    for (int i = 0; i < per; i++)
+        if (b0 + i < nbins) { const int c = cnt[b0 + i]; cnt[b0 + i] = run; run += c; }
+    __syncthreads();
+    for (int q = t; q < nq; q += 1024) qorder[atomicAdd(&cnt[bin_of(q)], 1)] = q;
+}
+
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank) {
     if (nq <= 0) return;
@@ -632,6 +673,13 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
     int shift = 0;
     while (((int64_t)nlist >> shift) > 16384) shift++;
     const int nbins = (int)(((int64_t)nlist - 1) >> shift) + 2;        // last bin: invalid keys
+    if (nq <= 2048) {
+        const size_t smem1 = (size_t)nbins * sizeof(int);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_single_kernel), smem1);
+        hipLaunchKernelGGL(qorder_single_kernel, dim3(1), dim3(1024), smem1, s, keys, (int)nq, nprobe, nlist, qorder, list_rank,
+                           shift, nbins);
+        return;
+    }
     const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
     (void)hipMemsetAsync(hist, 0, 2 * stride * sizeof(int), s);
     const unsigned g = (unsigned)((nq + 255) / 256);
