@@ -150,13 +150,16 @@ def test_error_paths(world):
         vlq.GpuVLQ(v.d, v.nlist, v.M, v.nbits, 4, 300)          # lambda index does not fit a byte
 
 
-@pytest.mark.parametrize("seed", range(16))
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VLQ_FUZZ_SEEDS_VLQ", "24"))))   # e.g. 300 for a soak run
 def test_random_vlq_configuration(seed):
     """Seeded random VLQ shapes (generic and 16-byte scan kernels, device-side add in batches,
     empty and over-long lines, w1 / k on both sides of the selection widths) against the oracle."""
     rng = np.random.default_rng(500 + seed)
-    M = int(rng.choice([2, 4, 8, 16, 16]))
-    nbits = 8 if M == 16 else int(rng.choice([4, 6, 8]))
+    M = int(rng.choice([2, 4, 8, 16, 16, 32]))     # 2: generic scan; 4 / 8 / 32 with small tables: lineS; 16 x 8: line16
+    nbits = 8 if M == 16 else (int(rng.choice([4, 5])) if M == 32 else int(rng.choice([4, 6, 8])))
     dsub = int(rng.choice([2, 4, 6, 8]))
     nlist = int(rng.choice([6, 20, 64]))
     nedge = int(rng.choice([1, 2, 5]))
