@@ -266,6 +266,67 @@ def sources_sha():
     return hh.hexdigest()
 
 
+def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
+    """The fork's VLQ index at the reference driver's geometry (65 536 centroids x 64 edges =
+    4.19 M lines, nLambda 256, M = 16 x 8 bit, nprobe 64, w1 1024, k 128; gpu/test/deep1b16_query.cpp:
+    206-208,326,337-340) with a reduced database: build on the device, search with fp32 and with float16
+    look-up tables (the drivers' setting), and check a query sample bit for bit against the VLQ oracle on
+    the lines the device selected.  Reported beside the headline, never instead of it."""
+    import vector_line_quantization_amd as vlq
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scale_checks
+    d, nlist, nedge, M, nprobe, w1, k = 96, 65536, 64, 16, 64, 1024, 128
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    cent = torch.rand((nlist, d), generator=gen, device=dev)
+    g = vlq.GpuVLQ(d, nlist, M, 8, nedge, 256, device=dev.index or 0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.set_coarse_centroids(cent)
+    t0 = time.time()
+    ei, ed = g.build_graph()
+    lam = np.linspace(-0.2, 1.2, 256).astype(np.float32)
+    g.set_lambda_codebook(lam)
+    pq = ((torch.rand((M, 256, d // M), generator=gen, device=dev) - 0.5) * 0.2).contiguous()
+    g.set_pq_centroids(pq)
+    first = None
+    for i in range(0, nb, 1000000):
+        n = min(1000000, nb - i)
+        pick = torch.randint(0, nlist, (n,), device=dev, generator=gen)
+        x = (cent[pick] + 0.08 * torch.randn((n, d), device=dev, generator=gen)).contiguous()
+        if first is None:
+            first = x[:nq].clone()
+        g.add(x)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    pick = torch.randint(0, nlist, (nq,), device=dev, generator=gen)
+    xq = (cent[pick] + 0.08 * torch.randn((nq, d), device=dev, generator=gen)).contiguous()
+    xq[:nq // 2] = first[:nq // 2]                      # half the batch: stored vectors
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    out = {"workload": "VLQ, SURVEY C5 geometry: d=96, 65536 centroids x 64 edges, nLambda=256, M=16x8bit, nprobe=64, w1=1024, "
+                       "k=128, %d queries per batch, %d synthetic vectors (reduced from 1 B; full size: profiles/)" % (nq, nb),
+           "build_s": build_s}
+    for name, fp16 in (("fp32_tables", False), ("float16_tables", True)):
+        g.set_float16_tables(fp16)
+        for _ in range(2):
+            g.search(xq, nprobe, w1, k, D=D, I=I)
+        torch.cuda.synchronize()
+        g.stats(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.search(xq, nprobe, w1, k, D=D, I=I)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        ncode = g.stats(reset=True) / reps
+        Ih = I.cpu().numpy()
+        s1, sk = scale_checks.self_hit(Ih[:nq // 2])
+        chk = scale_checks.check_vlq_sample(g, xq[np.r_[0:2, nq // 2:nq // 2 + 2]].cpu().numpy(), nprobe, w1, k, cent.cpu().numpy(),
+                                            pq.cpu().numpy(), lam, ei, ed, fp16=fp16)
+        out[name] = {"value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
+                     "self_hit_in_top_k": sk, "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +351,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-dataset", action="store_true")
     ap.add_argument("--no-host-buffers", action="store_true")
+    ap.add_argument("--no-vlq", action="store_true", help="skip the VLQ (configs[4] / SURVEY C5 geometry) leg")
     ap.add_argument("--cpu-queries", type=int, default=10000)
     args = ap.parse_args()
     defaults = {k: ap.get_default(k) for k in ("nq", "nb", "nt", "d", "nlist", "M", "nprobe", "k", "sigma",
@@ -614,6 +676,11 @@ def main():
         if world == 1 and default_workload and not fdir and not args.no_second_dataset:
             out["second_dataset"] = second_dataset(torch, args, dev)
 
+        if world == 1 and default_workload and not fdir and not args.no_vlq:
+            try:
+                out["vlq_c5_geometry"] = vlq_leg(torch, dev)
+            except Exception as e:     # noqa: BLE001 -- never lose the headline over the extra leg
+                out["vlq_c5_geometry"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             from oracle import pyoracle, refbench
             try:

@@ -20,7 +20,7 @@ def test_bench_collective_path_with_hip_index():
     e.update(BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
                         "--nb", "200000", "--nt", "50000", "--nlist", "1024", "--no-cpu-baseline", "--no-second-dataset",
-                        "--no-host-buffers"],
+                        "--no-host-buffers", "--no-vlq"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
