@@ -152,8 +152,10 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
         vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
                                             h->nlist, h->d, h->stream);
     } else {
+        // |q|^2: zeros for the VLQ path; otherwise computed inside the distance kernel (d <= 128) or by its own launch
+        const bool fused_norms = !zero_qnorm && vlq::coarse_norms_fused_ok(h->d);
         if (zero_qnorm) HIP_TRY(hipMemsetAsync(h->ws_qn.p, 0, (size_t)n * sizeof(float), h->stream));
-        else vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
+        else if (!fused_norms) vlq::launch_row_norms(x_dev, n, h->d, h->ws_qn.as<float>(), h->stream);
         if (argmin) {
             TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * 8));
             tmin = h->ws_tmin.as<float>();
@@ -161,7 +163,7 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
             TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * sizeof(float)));
             tmin = h->ws_tmin.as<float>();
         }
-        vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), h->ws_qn.as<float>(),
+        vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), fused_norms ? nullptr : h->ws_qn.as<float>(),
                                      h->cnorm.as<float>(), argmin ? nullptr : h->ws_dist.as<float>(), n,
                                      h->nlist, h->d, h->stream, tmin);
     }

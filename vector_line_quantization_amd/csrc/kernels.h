@@ -15,10 +15,12 @@ void ensure_dynamic_lds(const void* kernel, size_t bytes);
 void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s);
 
 // out[i][j] = (qn[i] + cn[j]) - 2 * <q_i, c_j>   (utils.cpp:884), inner product =
-// k-ordered f32 MFMA chain.  out is [nq][nlist].
+// k-ordered f32 MFMA chain.  out is [nq][nlist].  qn == nullptr (d <= 128 only, coarse_norms_fused_ok): the
+// kernel computes |q_i|^2 itself, in fvec_norm_L2sqr's order, from the query tile it stages anyway.
 // tmin != nullptr (only if coarse_tile_minima_ok): also tmin[i][t] = min of out[i][64t .. 64t+63]
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
                              float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin = nullptr);
+inline bool coarse_norms_fused_ok(int d) { return d <= 128; }
 // wide rows and few probes: the distance kernel can hand the select a [nq][nlist/64] matrix of tile minima
 bool coarse_tile_minima_ok(int nlist, int d, int nprobe);
 // 1-NN (the assignment of add / encode): out == nullptr and tmin = [nq][nlist / 64] 64-bit keys -- the

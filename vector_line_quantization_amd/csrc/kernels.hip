@@ -248,12 +248,24 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
 #pragma unroll
         for (int u = 0; u < NU; u++) areg[u] = *reinterpret_cast<const float4*>(src + 4 * u);
     }
+    // qn == nullptr: the query norms are computed here, from the staged tile, in the reference's own order
+    // (fvec_norms_L2sqr -> fvec_norm_L2sqr, utils.cpp:538-556, :675-682: norm_sse_order) -- one launch less
+    // per coarse call; element k of a staged row sits in parity plane k & 1 at column k >> 1
+    float* qns = sm + 2 * BUF + (TMIN == 1 ? 4 * 32 * 17 : 0);       // [128]
+    if (!qn) {
+        if (t < 128) {
+            const float* rowp = sm + (t >> 6) * BUF + (t & 63) * S;
+            qns[t] = norm_sse_order([&](int c) { return rowp[(c & 1) * 64 * S + (c >> 1)]; }, d);
+        }
+        __syncthreads();
+    }
     float qnr[16];
     float bnd[TMIN == 5 ? 16 : 1];
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
-        const int64_t row = i0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        qnr[reg] = qn[row < nq ? row : nq - 1];
+        const int lr = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int64_t row = i0 + lr;
+        qnr[reg] = qn ? qn[row < nq ? row : nq - 1] : qns[lr];
         if (TMIN == 5) bnd[reg] = flt.bound[(row < nq ? row : nq - 1) * flt.stride];
     }
     __syncthreads();
@@ -447,7 +459,8 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
                                float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s,
                                CoarseFilter flt = CoarseFilter{nullptr, 0, nullptr, nullptr, 0}) {
     constexpr int S = 4 * NU + 4;
-    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN == 1 ? (size_t)4 * 32 * 17 * sizeof(float) : 0);
+    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN == 1 ? (size_t)4 * 32 * 17 * sizeof(float) : 0) +
+                        128 * sizeof(float);      // + the fused query norms
     ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC, TMIN>), smem);
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
