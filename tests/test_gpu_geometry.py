@@ -227,3 +227,105 @@ def test_vlq_c5_recall_against_brute_force(vlq_c5):
         gt = int(np.argmin(d2)) * 3 + 1
         hit += gt in I[qi]
     assert hit >= 0.8 * xq.shape[0], hit
+
+
+# ----------------------------------------------------------------------------------------------
+# configs[3]: the Deep1B driver's flat-quantizer shape at ITS OWN list count
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def deep1b_own():
+    """BASELINE configs[3] (tests/deep1b_imi_pq.cpp shape with the flat 2^17-list quantizer the config names):
+    d = 96 (dsub = 6), nlist = 131 072, M = 16 x 8 bit, nprobe = 128.  The 2 GiB term2 table
+    ((size_t)key * E addressing), the 131 072-column coarse select from tile minima and the 16 384-row
+    distance-matrix pages (api.hip query_page) all run at full size; the database is 400 000
+    device-encoded vectors placed on the lists the checked queries probe (300 000 through encode +
+    set_lists, 100 000 appended on the device on top of them)."""
+    from oracle.pyoracle import OracleIndex
+    d, nlist, M, nprobe = 96, 131072, 16, 128
+    rng = np.random.default_rng(317)
+    coarse = rng.random((nlist, d), dtype=np.float32)
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    # 17 000 queries: one full 16 384-row page of the [page][nlist] matrix plus a tail page
+    nq, nhot = 17000, 192
+    xq = (coarse[rng.integers(0, nlist, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    xq[5] = coarse[77]                                   # a query sitting exactly on a centroid
+    _cd, keys = g.coarse_search(xq[:nhot], nprobe)
+    assert keys.min() >= 0 and keys.max() < nlist
+    # database vectors next to the centroids the first `nhot` queries probe (all 128 ranks), plus the
+    # far end of the key range so that the last rows of term2 are addressed
+    nb0, nb1 = 300000, 100000
+    qsel = rng.integers(0, nhot, nb0 + nb1)
+    jsel = rng.integers(0, nprobe, nb0 + nb1)
+    cen = keys[qsel, jsel]
+    cen[:500] = nlist - 1 - rng.integers(0, 4, 500)
+    xb = (coarse[cen] + 0.04 * rng.standard_normal((nb0 + nb1, d))).astype(np.float32)
+    xb[1000:1040] = xb[1000]                             # identical vectors: exact distance ties
+    assign, codes = g.encode(xb[:nb0])
+    order = np.argsort(assign, kind="stable")
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(np.bincount(assign, minlength=nlist), out=off[1:])
+    ids0 = (np.arange(nb0, dtype=np.int64) * 5 + 3)
+    g.set_lists(np.ascontiguousarray(codes[order]), ids0[order], off)
+    ids1 = (np.arange(nb0, nb0 + nb1, dtype=np.int64) * 5 + 3)
+    g.add(xb[nb0:], ids1)                                # device-side append on top of the loaded lists
+    assert g.ntotal == nb0 + nb1
+    # the lists as the device holds them -> oracle
+    lens = np.array([g.list_length(i) for i in range(nlist)], np.int64)
+    assert lens.sum() == nb0 + nb1 and lens[nlist - 4:].sum() >= 400
+    offo = np.zeros(nlist + 1, np.int64)
+    np.cumsum(lens, out=offo[1:])
+    codes_o = np.empty((nb0 + nb1, M), np.uint8)
+    ids_o = np.empty((nb0 + nb1,), np.int64)
+    for i in np.flatnonzero(lens):
+        c, ii = g.get_list(int(i))
+        codes_o[offo[i]:offo[i + 1]] = c
+        ids_o[offo[i]:offo[i + 1]] = ii
+    ox = OracleIndex(d, nlist, M, 8, coarse, pq, codes=codes_o, ids=ids_o, list_offsets=offo)
+    assert ox.precomputed_table.nbytes == 2 << 30        # the 2 GiB table of the config
+    return dict(g=g, ox=ox, xq=xq, xb=xb, nhot=nhot, nprobe=nprobe, lens=lens, ids=np.r_[ids0, ids1])
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_deep1b_own_geometry_full_search_bit_exact(deep1b_own, k):
+    """IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) at 2^17 lists x d 96 x nprobe 128 on a 17 000-query
+    batch (two distance-matrix pages): distances, labels and ncode of a sample, bit for bit."""
+    w = deep1b_own
+    g, ox, xq, nprobe = w["g"], w["ox"], w["xq"], w["nprobe"]
+    g.stats(reset=True)
+    D, I = g.search(xq, nprobe, k)
+    _n, ncode = g.stats(reset=True)
+    # the hot queries (their lists hold the codes), the on-centroid query, both sides of the page cut, the tail
+    sel = np.r_[0:40, 100:124, 16370:16400, 16990:17000]
+    Do, Io, keyso, _cdo = ox.search(xq[sel], nprobe, k, canonical=True, return_coarse=True)
+    assert np.array_equal(bits(D[sel]), bits(Do))
+    assert np.array_equal(I[sel], Io)
+    assert (I[:w["nhot"], 0] >= 0).all() and keyso.max() >= 1 << 16
+    # ncode of the whole batch = sum of the probed lists' lengths (IndexIVFPQ.cpp:1014,1035,1050)
+    _cd, keys = g.coarse_search(xq, nprobe)
+    assert ncode == int(w["lens"][keys].sum()) and ncode > w["nhot"] * 1000
+    # a stored vector finds itself
+    Ds, Is = g.search(w["xb"][:64], nprobe, 1)
+    assert (Is[:, 0] == w["ids"][:64]).mean() > 0.9
+
+
+def test_deep1b_own_geometry_preassigned_seam(deep1b_own):
+    """search_knn_with_key (IndexIVFPQ.h:140-146) at the same geometry: the oracle's own (keys, coarse_dis)
+    in, its distances / labels / ncode out; keys near 2^17 address the last rows of the 2 GiB table."""
+    w = deep1b_own
+    g, ox, xq, nprobe = w["g"], w["ox"], w["xq"], w["nprobe"]
+    sel = np.r_[0:48, 150:160]
+    cdo, keyso = ox.coarse_search(xq[sel], nprobe, canonical=True)
+    keyso = keyso.copy()
+    keyso[0, 3] = 131071                                  # last row of term2
+    keyso[1, 0] = -1                                      # skipped probe (IndexIVFPQ.cpp:1004-1007)
+    Do, Io = ox.search_preassigned(xq[sel], keyso, cdo, 100, canonical=True)
+    g.stats(reset=True)
+    Dp, Ip = g.search_preassigned(xq[sel], keyso, cdo, 100)
+    assert np.array_equal(bits(Dp), bits(Do)) and np.array_equal(Ip, Io)
+    assert g.stats(reset=True)[1] == ox.last_ncode
+    cd, keys = g.coarse_search(xq[sel], nprobe)
+    cdo2, keyso2 = ox.coarse_search(xq[sel], nprobe, canonical=True)
+    assert np.array_equal(keys, keyso2) and np.array_equal(bits(cd), bits(cdo2))

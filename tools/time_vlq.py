@@ -4,7 +4,10 @@ NB=1000000000): build on the device, time the search, and VERIFY it -- a sample 
 bit for bit against the VLQ oracle on the lines it selects, fetched back from the device, and stored
 vectors used as queries must come back (tests/scale_checks.py).
    python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D, CHECK (sample size, default 6),
-   FP16=1: float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)"""
+   FP16=1: float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)
+   SYNTH=1: the database is NB uniformly random (code, lambda) bytes loaded with set_lists, NB / lines per line --
+   the byte traffic of a populated index without the 150 s device-side build of 1 B vectors (recall is
+   meaningless then; the oracle check of a query sample on the device's own lines still applies)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,15 +31,29 @@ pq = ((rng.random((M, 1 << nbits, d // M), dtype=np.float32) - 0.5) * 0.2).astyp
 g.set_pq_centroids(pq)
 t0 = time.time()
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
-step = 1000000
-for i in range(0, nb, step):
-    n = min(step, nb - i)
-    pick = torch.randint(0, nlist, (n,), device="cuda", generator=gen)
-    x = torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((n, d), device="cuda", generator=gen)
-    if i == 0: first = x[:nq].clone()                   # stored vectors 0 .. nq-1 (sequential ids)
-    g.add(x.contiguous())
+synth = bool(E("SYNTH", 0))
+if synth:
+    nl = nlist * nedge
+    per = nb // nl
+    nb = per * nl
+    codes = torch.empty((nb, M), dtype=torch.uint8, device="cuda")
+    for i in range(0, nb, 1 << 26):
+        codes[i:i + (1 << 26)] = torch.randint(0, 256, (min(1 << 26, nb - i), M), dtype=torch.uint8, device="cuda", generator=gen)
+    lams = torch.randint(0, 256, (nb,), dtype=torch.uint8, device="cuda", generator=gen)
+    g.set_lists(codes, lams, torch.arange(nb, dtype=torch.int64, device="cuda"),
+                torch.arange(nl + 1, dtype=torch.int64, device="cuda") * per)
+    del codes, lams
+    first = torch.empty((0, d), device="cuda")
+else:
+    step = 1000000
+    for i in range(0, nb, step):
+        n = min(step, nb - i)
+        pick = torch.randint(0, nlist, (n,), device="cuda", generator=gen)
+        x = torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((n, d), device="cuda", generator=gen)
+        if i == 0: first = x[:nq].clone()                   # stored vectors 0 .. nq-1 (sequential ids)
+        g.add(x.contiguous())
 torch.cuda.synchronize()
-print("added %d vectors in %.1f s (%d lines, %.1f per line)" % (nb, time.time() - t0, nlist * nedge, nb / (nlist * nedge)), flush=True)
+print("%s %d vectors in %.1f s (%d lines, %.1f per line)" % ("loaded (synthetic codes)" if synth else "added", nb, time.time() - t0, nlist * nedge, nb / (nlist * nedge)), flush=True)
 pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
 xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
 nself = min(nq, first.shape[0]) // 2
@@ -63,7 +80,7 @@ print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import scale_checks
 Ih = I.cpu().numpy()
-s1, sk = scale_checks.self_hit(Ih[:nself])
+s1, sk = scale_checks.self_hit(Ih[:nself]) if nself else (1.0, 1.0)
 print("self-hit: %d stored vectors as queries: first %.4f, in top-%d %.4f" % (nself, s1, k, sk), flush=True)
 ns = E("CHECK", 6)
 pick = np.r_[0:ns // 2, nself:nself + ns - ns // 2]
