@@ -82,6 +82,14 @@ int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
  * whose term 2 entries reach 10^5 and become infinite. */
 int vlq_line_set_float16_tables(vlq_line_t h, int enable);
 
+/* Where the 16-byte scan takes a line's term-2 rows from (speed only: the results are bit-identical):
+ *   0 = automatic (rebuilt rows when the shape allows: M = 16 x 8 bit, dsub in {4, 6, 8}, k <= 256, fp32 tables)
+ *   1 = rows read from the stored [nlist][M][ksub] table, as the reference's kernel reads them
+ *       (impl/PQScanMultiPassPrecomputed.cu:54-75,313-334)
+ *   2 = rows rebuilt in registers from the far-end centroid and the PQ codebook (no term-2 table in HBM at all:
+ *       at 65 536 centroids that is 1 GiB less memory and 4/5 of the scan's HBM traffic) */
+int vlq_line_set_row_mode(vlq_line_t h, int mode);
+
 #ifdef __cplusplus
 }
 #endif

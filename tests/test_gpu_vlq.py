@@ -100,10 +100,13 @@ def test_line_cap_1024_codes():
     assert g.stats() == v.last_ncode < xq.shape[0] * 6000
 
 
-def test_m16_8bit_d128_shape():
-    """The 16-byte-code shape of the reference's deep1b16 / sift1b16 drivers."""
+@pytest.mark.parametrize("rows", [1, 2])
+def test_m16_8bit_d128_shape(rows):
+    """The 16-byte-code shape of the reference's deep1b16 / sift1b16 drivers; term-2 rows read from the
+    stored table (line16_scan_kernel) and rebuilt in registers (line16r_scan_kernel, dsub = 8)."""
     v, xb, xq = make_vlq(seed=5, d=128, nlist=32, M=16, nbits=8, nedge=8, nlambda=64, nb=4000)
     g = gpu_from_oracle(v)
+    g.set_row_mode(rows)
     D, I = g.search(xq, 8, 32, 10)
     Do, Io = v.search(xq, 8, 32, 10)
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
@@ -115,13 +118,17 @@ def world16():
     return make_vlq(seed=11, d=96, nlist=200, M=16, nbits=8, nedge=8, nlambda=256, nb=20000)
 
 
+@pytest.mark.parametrize("rows", [1, 2])
 @pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (16, 128, 128), (64, 300, 300), (8, 64, 1),
-                                         (128, 1024, 128), (200, 1024, 1000), (3, 5, 64)])
-def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k):
-    """line16_scan_kernel (anchor-grouped lines, compact line records, two-table gathers) against
-    the oracle over the selection sizes of the wave select (w1 -> 1/4/16 keys per lane, k likewise)."""
+                                         (128, 1024, 128), (200, 1024, 1000), (3, 5, 64), (64, 1024, 256)])
+def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k, rows):
+    """line16_scan_kernel (anchor-grouped lines, compact line records, two-table gathers; rows = 1) and
+    line16r_scan_kernel (term-2 rows rebuilt from the centroid and the codebook, interleaved double-buffered
+    table; rows = 2, k <= 256 -- larger selections fall back to the stored rows) against the oracle over the
+    selection sizes of the wave select (w1 -> 1/4/16 keys per lane, k likewise)."""
     v, _, xq = world16
     g = gpu_from_oracle(v)
+    g.set_row_mode(rows)
     D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
     Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
     assert np.array_equal(lines, lo)
@@ -129,10 +136,12 @@ def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k):
     assert g.stats() == v.last_ncode
 
 
-def test_m16_line_cap_and_big_batch():
+@pytest.mark.parametrize("rows", [1, 2])
+def test_m16_line_cap_and_big_batch(rows):
     v, xb, xq = make_vlq(seed=13, d=128, nlist=6, M=16, nbits=8, nedge=2, nlambda=32, nb=9000)
     assert np.diff(v.line_off).max() > 1024
     g = gpu_from_oracle(v)
+    g.set_row_mode(rows)
     xq = np.concatenate([xq] * 30)          # 1200 queries: several waves of workgroups
     D, I = g.search(xq, 6, 12, 20)
     Do, Io = v.search(xq, 6, 12, 20)
@@ -183,6 +192,10 @@ def test_random_vlq_configuration(seed):
     Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
     assert np.array_equal(lines, lo)
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    if M == 16:        # the automatic choice above rebuilt the term-2 rows where it could; the stored rows agree
+        g.set_row_mode(1)
+        D1, I1 = g.search(xq, nprobe, w1, k)
+        assert np.array_equal(bits(D1), bits(Do)) and np.array_equal(I1, Io)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ struct LineScanArgs {
     // float16 look-up tables (useFloat16LookupTables, 16-byte scan only): half(term2) and half(-2 <q_m, cent_mj>)
     const uint16_t* term2h = nullptr;    // [nlist][M*ksub]
     const uint16_t* qtabh = nullptr;     // [nq][M*ksub]
+    // row-recomputing 16-byte scan (line16r.hip): coarse centroids, PQ codebook [M][ksub][dsub] and its norms
+    const float* coarse = nullptr;       // [nlist][d]
+    const float* pq_cent = nullptr;      // [M][ksub][dsub]
+    const float* pq_rnorm = nullptr;     // [M][ksub]
     const int32_t* edge_info;    // [nlist*nedge]
     const float* edge_dist;      // [nlist*nedge]
     const float* lambda_info;    // [nlambda]
@@ -61,6 +65,10 @@ struct LineScanArgs {
     int w1, k, M, ksub, nedge, max_line_codes;
 };
 void launch_line_scan(const LineScanArgs& a, hipStream_t s);
+// 16-byte codes, term-2 rows rebuilt in registers instead of read (line16r.hip): same results as
+// launch_line_scan, bit for bit
+bool line16r_supports(const LineScanArgs& a, int dsub);
+void launch_line16r_scan(const LineScanArgs& a, int dsub, hipStream_t s);
 // out[i] = half(scale * in[i]) (round to nearest even); scale = 1 (term 2) or -2 (term 3, IVFPQ.cu:1409-1442)
 void launch_to_half(const float* in, int64_t n, float scale, uint16_t* out, hipStream_t s);
 

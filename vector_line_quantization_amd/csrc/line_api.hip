@@ -14,6 +14,7 @@ struct vlq_line_s {
     bool have_graph = false, have_lambda = false;
     // float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables): half(term2), built on demand
     bool fp16_tables = false, term2h_valid = false;
+    int row_mode = 0;                    // vlq_line_set_row_mode: 0 auto, 1 stored term-2 rows, 2 rebuilt rows
     DevBuf term2h, ws_qtabh;
     std::vector<int64_t> h_line_off, h_line_len;
     bool h_lines_stale = false;
@@ -132,6 +133,13 @@ void vlq_line_destroy(vlq_line_t h) {
 int vlq_line_set_stream(vlq_line_t h, void* s) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     return vlq_ivfpq_set_stream(h->base, s);
+}
+
+int vlq_line_set_row_mode(vlq_line_t h, int mode) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (mode < 0 || mode > 2) return fail(VLQ_ERR_INVALID, "row mode %d outside 0..2", mode);
+    h->row_mode = mode;
+    return VLQ_OK;
 }
 
 int vlq_line_set_float16_tables(vlq_line_t h, int enable) {
@@ -368,8 +376,11 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
     TRY(vlq_ivfpq_set_search_options(b, 1, 1, 0));
-    TRY(ensure_term2(b));
     nprobe = std::min(nprobe, b->nlist);          // IVFPQ.cu:702
+    // rows rebuilt in the scan kernel (line16r.hip) need no term-2 table at all
+    const bool rebuilt_rows = h->row_mode != 1 && !h->fp16_tables && b->M == 16 && b->ksub == 256 && k <= 256 &&
+                              (b->dsub == 4 || b->dsub == 6 || b->dsub == 8) && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
+    if (!rebuilt_rows) TRY(ensure_term2(b));
     const size_t E = (size_t)b->M * b->ksub;
     const void* xd;
     TRY(stage_in(b, x, (size_t)n * b->d * 4, h->ws_x, &xd));
@@ -418,7 +429,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         // 4. scan + top-k
         vlq::LineScanArgs a;
         a.codes = h->codes.as<uint8_t>(); a.lambdas = h->lambdas.as<uint8_t>(); a.ids = h->ids.as<int64_t>();
-        a.line_off = h->line_off.as<int64_t>(); a.line_len = h->line_len.as<int64_t>(); a.term2 = b->term2.as<float>(); a.qtab = b->ws_qtab.as<float>();
+        a.line_off = h->line_off.as<int64_t>(); a.line_len = h->line_len.as<int64_t>(); a.term2 = rebuilt_rows ? nullptr : b->term2.as<float>(); a.qtab = b->ws_qtab.as<float>();
         a.edge_info = h->edge_info.as<int32_t>(); a.edge_dist = h->edge_dist.as<float>();
         a.lambda_info = h->lambda_info.as<float>();
         a.sel_line = sel_line; a.sel_b2 = h->ws_sel_b2.as<float>(); a.sel_g = h->ws_sel_g.as<float>();
@@ -428,7 +439,13 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.ncode = h->stats.as<unsigned long long>();
         a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;
         a.max_line_codes = VLQ_LINE_MAX_CODES;
-        vlq::launch_line_scan(a, b->stream);
+        if (rebuilt_rows) {
+            a.coarse = b->coarse.as<float>(); a.pq_cent = b->pq.as<float>(); a.pq_rnorm = b->rnorm.as<float>();
+            a.term2 = nullptr;
+            vlq::launch_line16r_scan(a, b->dsub, b->stream);
+        } else {
+            vlq::launch_line_scan(a, b->stream);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (lines_out) HIP_TRY(hipMemcpyAsync(lines_out, h->ws_sel_line.p, (size_t)n * w1 * 4, hipMemcpyDeviceToHost, b->stream));

@@ -254,6 +254,11 @@ class GpuVLQ:
         """GpuIndexIVFPQConfig::useFloat16LookupTables for the VLQ search (include/vlq_line.h)"""
         check(lib().vlq_line_set_float16_tables(self._h, C.c_int(int(enable))))
 
+    def set_row_mode(self, mode):
+        """0 automatic, 1 term-2 rows read from the stored table, 2 rows rebuilt in the scan kernel
+        (speed only, identical results; include/vlq_line.h)"""
+        check(lib().vlq_line_set_row_mode(self._h, C.c_int(int(mode))))
+
     def set_graph(self, edge_info, edge_dist):
         pe, _a = _ptr(edge_info, np.int32)
         pd, _b = _ptr(edge_dist, np.float32)
