@@ -82,12 +82,14 @@ int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
  * whose term 2 entries reach 10^5 and become infinite. */
 int vlq_line_set_float16_tables(vlq_line_t h, int enable);
 
-/* Where the 16-byte scan takes a line's term-2 rows from (speed only: the results are bit-identical):
- *   0 = automatic (rebuilt rows when the shape allows: M = 16 x 8 bit, dsub in {4, 6, 8}, k <= 256, fp32 tables)
- *   1 = rows read from the stored [nlist][M][ksub] table, as the reference's kernel reads them
- *       (impl/PQScanMultiPassPrecomputed.cu:54-75,313-334)
- *   2 = rows rebuilt in registers from the far-end centroid and the PQ codebook (no term-2 table in HBM at all:
- *       at 65 536 centroids that is 1 GiB less memory and 4/5 of the scan's HBM traffic) */
+/* Where the 16-byte scan takes a line's term-2 rows from (speed / memory only: the results are bit-identical):
+ *   0, 1 = rows read from the stored [nlist][M][ksub] table, as the reference's kernel reads them
+ *       (impl/PQScanMultiPassPrecomputed.cu:54-75,313-334); 0 = "automatic" resolves to this, the faster one
+ *   2 = rows rebuilt in registers from the far-end centroid and the PQ codebook (line16r.hip; M = 16 x 8 bit,
+ *       dsub in {4, 6, 8}, k <= 256, fp32 tables -- other shapes keep the stored rows): no term-2 table in HBM
+ *       at all (1 GiB less at 65 536 centroids) and a quarter of the scan's HBM traffic (11 against 45 GB per
+ *       2000 queries at the reference driver's geometry), paid for with 2.7x the VALU work: 8.8 against 7.1 ms
+ *       there.  For memory-constrained deployments; not the default. */
 int vlq_line_set_row_mode(vlq_line_t h, int mode);
 
 #ifdef __cplusplus

@@ -5,6 +5,7 @@ bit for bit against the VLQ oracle on the lines it selects, fetched back from th
 vectors used as queries must come back (tests/scale_checks.py).
    python tools/time_vlq.py [nq] [reps]   env: NB, NLIST, NEDGE, NPROBE, W1, K, D, CHECK (sample size, default 6),
    FP16=1: float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)
+   ROWS=1|2: vlq_line_set_row_mode (default 0 = automatic)
    SYNTH=1: the database is NB uniformly random (code, lambda) bytes loaded with set_lists, NB / lines per line --
    the byte traffic of a populated index without the 150 s device-side build of 1 B vectors (recall is
    meaningless then; the oracle check of a query sample on the device's own lines still applies)"""
@@ -58,6 +59,7 @@ pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
 xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
 nself = min(nq, first.shape[0]) // 2
 xq[:nself] = first[:nself]                              # half the batch: stored vectors
+if E("ROWS", 0): g.set_row_mode(E("ROWS", 0))            # 1: term-2 rows from the stored table, 2: rebuilt in the kernel
 fp16 = bool(E("FP16", 0))
 if fp16 or (M == 16 and nbits == 8): g.set_float16_tables(fp16)
 print("look-up tables: %s" % ("float16" if fp16 else "float32"), flush=True)

@@ -378,7 +378,7 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
     TRY(vlq_ivfpq_set_search_options(b, 1, 1, 0));
     nprobe = std::min(nprobe, b->nlist);          // IVFPQ.cu:702
     // rows rebuilt in the scan kernel (line16r.hip) need no term-2 table at all
-    const bool rebuilt_rows = h->row_mode != 1 && !h->fp16_tables && b->M == 16 && b->ksub == 256 && k <= 256 &&
+    const bool rebuilt_rows = h->row_mode == 2 && !h->fp16_tables && b->M == 16 && b->ksub == 256 && k <= 256 &&
                               (b->dsub == 4 || b->dsub == 6 || b->dsub == 8) && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
     if (!rebuilt_rows) TRY(ensure_term2(b));
     const size_t E = (size_t)b->M * b->ksub;
