@@ -185,7 +185,7 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, enable ? 1 : 0, 0));
   }
   bool getPrecomputedCodes() const { return usePrecomputed_; }
-  /// what the caller asked for (the tables themselves are fp32 here, see verifyConfig_)
+  /// what the caller asked for (honoured by the VLQ search with 16 x 8-bit codes; see verifyConfig_)
   bool getFloat16LookupTables() const { return ivfpqConfig_.useFloat16LookupTables; }
   int getNumSubQuantizers() const { return subQuantizers_; }
   int getBitsPerCode() const { return bitsPerCode_; }

@@ -114,7 +114,8 @@ int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len);
 int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* ids_out);
 
 /* Scheduling of the 16-byte-code scan kernel -- SPEED ONLY, results are identical in every mode:
- *   0  automatic (chosen per index when the coarse centroids are set)
+ *   0  automatic: query-major today -- the list-owned schedule moves fewer bytes but is slower on every data
+ *      set measured, so nothing selects it by itself
  *   1  query-major: one workgroup per query walks all its probes
  *   2  list-owned: the lists are cut into 8 partitions of neighbouring lists, one per XCD; one workgroup
  *      per (query, partition) scans the query's probes of that partition, a merge joins the parts.  Keeps

@@ -62,6 +62,7 @@ def test_full_batch_vs_compiled_reference(world, tmp_path):
     # chain (unpinned by construction): rows whose probe sets agree -- decided by the
     # row's distances agreeing bit for bit -- must agree in EVERY slot; the others are counted and bounded
     row_eq = (D.view(np.uint32) == Dr.view(np.uint32)).all(axis=1)
+    print("rows bit-equal to the compiled reference in every distance: %d of %d (%.5f)" % (row_eq.sum(), row_eq.shape[0], row_eq.mean()))
     assert row_eq.mean() >= 0.999, row_eq.mean()
     assert label_agreement(D[row_eq], I[row_eq], Dr[row_eq], Ir[row_eq]) == 1.0
     same = I == Ir

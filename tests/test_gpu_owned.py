@@ -84,3 +84,38 @@ def test_owned_reports_invalid_keys(world):
     with pytest.raises(vlq.VlqError):
         g2.search_preassigned(xq, keys, cd, 5)
     g2.stats(reset=True)
+
+
+def test_owned_reports_a_row_of_only_invalid_keys(world):
+    """A query whose probes are ALL >= nlist has no (query, partition) item, hence no scan workgroup: the merge
+    kernel raises the flag, as the query-major kernel does (the two schedules behave alike in every case)."""
+    ox, g1, g2, xq = world
+    cd, keys = g1.coarse_search(xq, 16)
+    keys = keys.copy()
+    keys[11, :] = 512 + np.arange(16)
+    for g in (g1, g2):
+        with pytest.raises(vlq.VlqError):
+            g.search_preassigned(xq, keys, cd, 5)
+        g.stats(reset=True)
+
+
+def test_bad_key_flag_keeps_the_counters(world):
+    """vlq_ivfpq_stats(reset = 0) consumes the flag it reports but leaves ncode alone."""
+    import torch
+    ox, g1, g2, xq = world
+    cd, keys = g1.coarse_search(xq, 16)
+    g1.stats(reset=True)
+    D, I = g1.search_preassigned(xq, keys, cd, 5)
+    _nq, ncode = g1.stats()
+    assert ncode > 0
+    bad = keys.copy()
+    bad[3, 0] = 1 << 40
+    xd, kd, cdd = (torch.from_numpy(a).cuda() for a in (xq, bad, cd))
+    Dd = torch.empty((xq.shape[0], 5), dtype=torch.float32, device="cuda")
+    Id = torch.empty((xq.shape[0], 5), dtype=torch.int64, device="cuda")
+    g1.search_preassigned(xd, kd, cdd, 5, D=Dd, I=Id)      # device outputs: the error surfaces lazily
+    with pytest.raises(vlq.VlqError):
+        g1.stats()
+    _nq, ncode2 = g1.stats()                                # flag consumed, counters kept
+    assert ncode2 >= 2 * ncode - 64 * 4096
+    g1.stats(reset=True)

@@ -7,7 +7,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.environ.get("VLQ_LIB_PATH") or os.path.join(_CSRC, "libvlq_ivfpq.so")   # override: kernel experiments
+_SO = os.environ.get("VLQ_LIB_PATH") or os.path.join(_CSRC, "libvlq_ivfpq.so")   # override: A/B builds of the library
 
 # every symbol include/vlq_ivfpq.h declares
 SYMBOLS = [

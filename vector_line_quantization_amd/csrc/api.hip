@@ -306,14 +306,10 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.store_pairs = store_pairs;
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
         a.long_lists = h->ntotal >= (int64_t)h->nlist * 1024;   // mean list >= 4 chunks of 256 codes
-#ifdef VLQ_EXPERIMENTS
-        if (getenv("VLQ_NOPIPE")) a.long_lists = 0;
-        if (getenv("VLQ_PIPE")) a.long_lists = 1;
-#endif
         if (fast16) {
             // scan schedule (speed only): list-owned = one workgroup per (query, list partition), XCD x
             // serves the lists of partition x, so their term2 rows and codes stay in that XCD's L2
-            const int sched = h->scan_schedule ? h->scan_schedule : h->auto_schedule;
+            const int sched = h->scan_schedule ? h->scan_schedule : 1;     // 0 = automatic = query-major (the faster one on every data set measured)
             const bool owned = sched == 2 && h->imi_nbits == 0 && h->have_rank && h->nlist >= 64 && h->nlist <= 16384 &&
                                ni >= 1024 && nprobe >= 8 && h->dsub == 8 && h->ntotal >= (int64_t)h->nlist * 24;
             if (owned) {
@@ -359,19 +355,6 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 tq.stop();
             }
             StageTimer tm(h, 2);       // exactly the scan kernel
-#ifdef VLQ_EXPERIMENTS
-            // kernel experiments (make libvlq_exp.so): never in the product library
-            static const char* variant = getenv("VLQ_SCAN16");
-            if (variant && variant[0] == '2') vlq::launch_scan16v2(a, h->stream);
-            else if (variant && variant[0] == 'p' && a.qorder && vlq::scan16p_supports(a)) vlq::launch_scan16p(a, h->stream);
-            else if (variant && variant[0] == 'w') vlq::launch_scan16w(a, variant[1] == '2' ? 2 : variant[1] == '1' ? 1 : 4, h->stream);
-            else if (variant && variant[0] == 's' && k <= 64 && h->imi_nbits == 0 && ni >= 1024) {
-                // persistent "stream" kernel (experiments/scan16s.hip): s = overlapped, s0 = serial
-                if (h->ws_own_count.reserve(64) != VLQ_OK) return VLQ_ERR_HIP;
-                a.own_next = h->ws_own_count.as<int>();
-                vlq::launch_scan16_stream(a, h->stream, variant[1] == '0' ? 0 : 1);
-            } else
-#endif
             if (h->ntotal < (int64_t)h->nlist * 24) vlq::launch_scan16_short(a, h->stream);   // a few codes per list
             else {
                 // fewer workgroups than the chip holds (256 CUs x 4): split every query's probes over
@@ -429,6 +412,13 @@ int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t by
     return VLQ_OK;
 }
 
+// device flag word of h->stats: 1 = a probe key >= nlist (the caller's error), 2 = a scan kernel found static LDS
+// in front of its look-up tables (a build fault of this library: the gathers use absolute LDS offsets)
+int bad_flag_error(int bad) {
+    if (bad == 2) return fail(VLQ_ERR_HIP, "internal: a 16-byte scan kernel was built with static LDS (its table offsets are absolute)");
+    return fail(VLQ_ERR_INVALID, "a probe key >= nlist was passed to search_preassigned (IndexIVFPQ.cpp:1008-1011)");
+}
+
 // An out-of-range probe key aborts the reference's search (IndexIVFPQ.cpp:1008-1011).  The scan
 // kernels raise a device flag; call this after the stream has been synchronised (host outputs).
 int read_bad_key(vlq_ivfpq_t h) {
@@ -436,7 +426,7 @@ int read_bad_key(vlq_ivfpq_t h) {
     HIP_TRY(hipMemcpy(&bad, reinterpret_cast<const char*>(h->stats.p) + 8, sizeof(int), hipMemcpyDeviceToHost));
     if (!bad) return VLQ_OK;
     HIP_TRY(hipMemset(reinterpret_cast<char*>(h->stats.p) + 8, 0, 8));
-    return fail(VLQ_ERR_INVALID, "a probe key >= nlist was passed to search_preassigned (IndexIVFPQ.cpp:1008-1011)");
+    return bad_flag_error(bad);
 }
 
 }  // namespace
@@ -480,7 +470,10 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(VLQ_ERR_HIP, "device init failed: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    if (const char* e = getenv("VLQ_SCAN_SCHEDULE")) h->scan_schedule = atoi(e);   // tests / experiments: 1 query-major, 2 list-owned
+    if (const char* e = getenv("VLQ_SCAN_SCHEDULE")) {    // tests / A-B runs: 1 query-major, 2 list-owned; anything else is ignored
+        const int m = atoi(e);
+        if (m >= 0 && m <= 2) h->scan_schedule = m;
+    }
     if (const char* e = getenv("VLQ_COARSE_FILTER")) h->coarse_filter = atoi(e);   // 1: filtered coarse stage (A/B; slower)
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
     int rc = h->stats.reserve(16);
@@ -863,12 +856,14 @@ int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
     if (nq) *nq = h->stat_nq;
     if (ncode) *ncode = st[0];
     const int bad = (int)(st[1] & 0xffffffffu);
-    if (reset || bad) {
+    if (reset) {
         HIP_TRY(hipMemsetAsync(h->stats.p, 0, 16, h->stream));
-        if (reset) h->stat_nq = 0;
+        h->stat_nq = 0;
+    } else if (bad) {       // the flag is consumed by the error it raises; the counters stay
+        HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(h->stats.p) + 8, 0, 8, h->stream));
     }
     // the reference aborts the search on an out-of-range key (IndexIVFPQ.cpp:1008-1011)
-    if (bad) return fail(VLQ_ERR_INVALID, "a probe key >= nlist was passed to search_preassigned");
+    if (bad) return bad_flag_error(bad);
     return VLQ_OK;
 }
 

@@ -90,7 +90,6 @@ struct ScanArgs {
     const uint8_t* list_part = nullptr;      // [nlist] partition 0..7 of every list
     const int* own_order = nullptr;          // [8][nq] the queries with probes in partition x, scheduling order
     const int* own_count = nullptr;          // [8]
-    int* own_next = nullptr;                 // [8] per-XCD work-queue heads of the stream kernel (scan16s.hip)
     unsigned long long* part_keys = nullptr; // [nq][8][k]
     const uint8_t* part_mask = nullptr;      // [nq] bit x: the query has a probe in partition x
     int qtab_scaled = 0;                     // qtab already holds (-2) * <q_m, cent_mj>
@@ -108,20 +107,10 @@ inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
 void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
 void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
 void launch_owned_merge(const ScanArgs& a, hipStream_t s);
-// same shape, k <= 64: persistent workgroups that overlap a query's set-up and merge with the probes of
-// its neighbours (scan16s.hip); a.own_next = 8 ints of device scratch (zeroed by the launcher)
-void launch_scan16_stream(const ScanArgs& a, hipStream_t s, int overlap);
 // same shape, 256 < k <= 1024: one selection per workgroup instead of one per wave (scan16k.hip)
 void launch_scan16_bigk(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
 void launch_scan16_short(const ScanArgs& a, hipStream_t s);
-// second generation: whole-probe prefetch, scalar list bases (scan16v2.hip)
-void launch_scan16v2(const ScanArgs& a, hipStream_t s);
-// wave-autonomous variant (scan16w.hip): nw = 2 or 4 waves per workgroup
-void launch_scan16w(const ScanArgs& a, int nw, hipStream_t s);
-// two neighbouring queries per workgroup, shared lists scanned once (scan16p.hip); needs a.qorder
-bool scan16p_supports(const ScanArgs& a);
-void launch_scan16p(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
 // ints of scratch launch_query_order needs in `hist`: 2 x this
 inline size_t query_order_bins_padded(int nlist) {

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void owned_merge_kernel(ScanArgs a, int stride
     ProbeMeta pm;
     pm.carve(base + 512, a.nprobe);
     const int64_t* kq = a.keys + q * a.nprobe;
-    probe_meta_fill(a, q, pm, lane, 64);
+    if (probe_meta_fill(a, q, pm, lane, 64)) *a.bad_key = 1;     // a query whose probes are all invalid has no scan workgroup
     __builtin_amdgcn_wave_barrier();
     probe_meta_scan(a, pm, lane);
     __builtin_amdgcn_wave_barrier();
@@ -559,13 +559,6 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     if (lutb < merge) lutb = merge;
     const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
     const size_t smem = lutb + tail;
-#ifdef VLQ_EXPERIMENTS
-    if (getenv("VLQ_FORCE_KPL4")) {     // the k > 64 kernel on a small k: separates code structure from insertion statistics
-        if (a.long_lists) launch_scan16_t<4, 4, 2, true>(a, (int)lutb, smem, s);
-        else launch_scan16_t<4, 4, 2, false>(a, (int)lutb, smem, s);
-        return;
-    }
-#endif
     if (a.k <= 64) launch_scan16_t<1, 4, 2, true>(a, (int)lutb, smem, s);
     else if (a.k <= 128) {          // recall@100: half the merge network of the 256-key list
         if (a.long_lists) launch_scan16_t<2, 4, 2, true>(a, (int)lutb, smem, s);
