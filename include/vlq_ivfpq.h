@@ -106,6 +106,10 @@ int vlq_ivfpq_reclaim_memory(vlq_ivfpq_t h, uint64_t* bytes_reclaimed);
 /* Encode only: assign[n] i64 and codes[n][M] u8 (IndexIVFPQ::encode_multiple with
  * compute_keys=true, IndexIVFPQ.cpp:150-167).  Outputs [h|d]. */
 int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, uint8_t* codes);
+/* The same with the lists given: codes[n][M] of x for assign[n] (IndexIVFPQ::encode_multiple with
+ * compute_keys = false, IndexIVFPQ.cpp:150-167; the `precomputed_idx` path of add_core_o, :192-211).  A vector
+ * with assign < 0 is encoded as if its residual were zero (IndexIVFPQ.cpp:219-221).  All buffers [h|d]. */
+int vlq_ivfpq_encode_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* assign, uint8_t* codes);
 
 int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h);
 /* GpuIndexIVFPQ::getListLength / getListCodes / getListIndices

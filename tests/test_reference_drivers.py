@@ -1,0 +1,82 @@
+"""INTEGRATION.md section B executed: the REFERENCE's own driver tests/demo_sift1M.cpp, compiled in place from
+/root/reference/tests (tests/cpp/Makefile `ref_drivers`, build container only) and linked with the reference's own
+CPU library plus integration/reference_interposer.cpp in front of it, runs on the MI355X without a changed line:
+index_factory("IVF4096,PQ8+16") -> IndexIVFPQR -> IndexIVFPQ::search_knn_with_key lands in
+vlq_ivfpq_search_preassigned.  The SAME binary with VLQ_INTERPOSE=off is the CPU-only run it is compared with.
+
+The driver auto-tunes (ParameterSpace::explore): which operating points it visits and which one it selects depends
+on measured times, so the comparison is made where both runs did the same thing -- every operating point both
+runs report must have the same 1-recall@1, and when both select the same configuration the final R@1 / R@10 /
+R@100 lines must be equal.  The generated data have real-valued coordinates (no exact distance ties)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RD = os.path.join(ROOT, "tests", "cpp", "ref_drivers")
+
+
+def _env(extra):
+    e = dict(os.environ)
+    e["LD_LIBRARY_PATH"] = os.path.join(ROOT, "oracle/_ref/mkl") + ":" + e.get("LD_LIBRARY_PATH", "")
+    e["OMP_NUM_THREADS"] = "8"            # the reference's OpenMP loops: never one spinning thread per logical CPU
+    e["OMP_WAIT_POLICY"] = "passive"
+    e.update(extra)
+    return e
+
+
+def _parse(out):
+    pts = {m.group(1): float(m.group(2)) for m in re.finditer(r"cno=\d+ key=(\S+) perf=([0-9.]+)", out)}
+    sel = re.search(r'Setting parameter configuration "([^"]*)"', out)
+    rec = tuple(re.findall(r"R@(?:1|10|100) = ([0-9.]+)", out)[-3:])
+    return pts, (sel.group(1) if sel else None), rec
+
+
+def test_interposer_exports_the_reference_symbols():
+    """CPU: the prebuilt interposer defines the three member functions under the reference's mangled names."""
+    so = os.path.join(RD, "libvlq_interpose.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for s in ("_ZNK5faiss10IndexIVFPQ19search_knn_with_keyEmPKfPKlS2_PNS_9HeapArrayINS_4CMaxIflEEEEb",
+              "_ZN5faiss10IndexIVFPQ10add_core_oElPKfPKlPfS4_", "_ZN5faiss10IndexIVFPQ16precompute_tableEv"):
+        assert s in syms, s
+    for exe in ("demo_sift1M", "sift1b_imi_pq"):
+        assert os.access(os.path.join(RD, exe), os.X_OK)
+
+
+@pytest.mark.gpu
+def test_demo_sift1M_unchanged_on_the_device(tmp_path):
+    exe = os.path.join(RD, "demo_sift1M")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
+        pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
+    data = str(tmp_path / "data")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "40000", "200000", "1000"])
+    runs = {}
+    for mode in ("off", "on"):
+        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
+                           timeout=900, cwd=str(tmp_path))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        runs[mode] = (p.stdout, p.stderr)
+    pts_c, sel_c, rec_c = _parse(runs["off"][0])
+    pts_d, sel_d, rec_d = _parse(runs["on"][0])
+    print("cpu  :", sel_c, rec_c, len(pts_c), "operating points")
+    print("device:", sel_d, rec_d, len(pts_d), "operating points")
+    summ = re.search(r"\[vlq-interpose\] device searches=(\d+) queries=(\d+) ncode=(\d+) .*cpu_fallbacks=(\d+)", runs["on"][1])
+    assert summ, runs["on"][1][-500:]
+    print(summ.group(0))
+    searches, queries, ncode = (int(summ.group(i)) for i in (1, 2, 3))
+    assert searches >= 5 and queries >= 5000 and ncode > 10 ** 7        # the plain (ht = 64) operating points ran on the device
+    off = re.search(r"\[vlq-interpose\] device searches=(\d+)", runs["off"][1])
+    assert off and int(off.group(1)) == 0                                # ... and nothing did in the CPU-only run
+    common = sorted(set(pts_c) & set(pts_d) - {""})
+    assert len(common) >= 3, (pts_c, pts_d)
+    for key in common:
+        assert pts_c[key] == pts_d[key], (key, pts_c[key], pts_d[key])
+    assert any("ht=64" in k for k in common)
+    assert len(rec_c) == 3 and len(rec_d) == 3
+    if sel_c and sel_c == sel_d:
+        assert rec_c == rec_d

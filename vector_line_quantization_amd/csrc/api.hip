@@ -925,6 +925,24 @@ int vlq_ivfpq_encode(vlq_ivfpq_t h, int64_t n, const float* x, int64_t* assign, 
     return finish_outputs(h, copy_a, assign, ad, (size_t)n * 8, copy_c, codes, cd, (size_t)n * h->M);
 }
 
+int vlq_ivfpq_encode_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* assign, uint8_t* codes) {
+    TRY(check_ready(h, false));
+    if (n < 0 || (n > 0 && (!x || !assign || !codes))) return fail(VLQ_ERR_INVALID, "bad argument");
+    if (n == 0) return VLQ_OK;
+    TRY(set_dev(h));
+    const void *xd, *ad;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    TRY(stage_in(h, assign, (size_t)n * 8, h->ws_assign, &ad));
+    void* cd;
+    bool copy_c;
+    TRY(stage_out(codes, (size_t)n * h->M, h->ws_codes, &cd, &copy_c));
+    vlq::launch_residual_encode((const float*)xd, n, h->d, h->imi_nbits > 0 ? h->imi_cent.as<float>() : h->coarse.as<float>(),
+                                (const int64_t*)ad, h->by_residual, h->pq.as<float>(), h->M, h->ksub, h->dsub, (uint8_t*)cd,
+                                h->stream, h->imi_nbits);
+    HIP_TRY(hipGetLastError());
+    return finish_outputs(h, false, nullptr, nullptr, 0, copy_c, codes, cd, (size_t)n * h->M);
+}
+
 int vlq_ivfpq_add(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* xids) {
     TRY(check_ready(h, false));
     if (n < 0 || (n > 0 && !x)) return fail(VLQ_ERR_INVALID, "bad argument");

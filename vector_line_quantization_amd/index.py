@@ -139,6 +139,15 @@ class GpuIVFPQ:
         return assign, codes
 
     # --- search -----------------------------------------------------------
+    def encode_preassigned(self, x, assign):
+        """codes of x for the given lists (IndexIVFPQ::encode_multiple, compute_keys = false)"""
+        n = x.shape[0]
+        px, _a = _ptr(x, np.float32)
+        pa, _b = _ptr(assign, np.int64)
+        codes = np.empty((n, self.M), np.uint8)
+        check(lib().vlq_ivfpq_encode_preassigned(self._h, C.c_int64(n), px, pa, codes.ctypes.data_as(C.c_void_p)))
+        return codes
+
     def _out(self, out, shape, dtype, like):
         if out is not None:
             return out
