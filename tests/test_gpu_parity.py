@@ -502,19 +502,22 @@ def test_encode_preassigned_matches_encode():
     (IndexIVFPQ.cpp:219-221)."""
     case = Case("c1_small")
     g = gpu_index(case, with_lists=False)
-    assign, codes = g.encode(case.xb[:3000])
-    assert np.array_equal(g.encode_preassigned(case.xb[:3000], assign), codes)
+    x = case.xb[:3000]
+    assign, codes = g.encode(x)
+    assert np.array_equal(g.encode_preassigned(x, assign), codes)
     a2 = assign.copy()
     a2[::7] = (a2[::7] + 1) % case.nlist              # other lists: other residuals
     a2[5] = -1
-    c2 = g.encode_preassigned(case.xb[:3000], a2)
-    ox = case.oracle_index(with_lists=False)
-    co = ox.encode_preassigned(case.xb[:3000], a2) if hasattr(ox, "encode_preassigned") else None
-    if co is not None:
-        assert np.array_equal(c2, co)
+    c2 = g.encode_preassigned(x, a2)
     same = a2 == assign
-    assert np.array_equal(c2[same], codes[same]) and not np.array_equal(c2[~same], codes[~same])
-    zero = g.encode_preassigned(np.zeros((1, case.d), np.float32), np.array([-1], np.int64))
-    assert np.array_equal(zero[0], c2[5]) or True     # both are the code of the zero residual only if x = 0: checked below
-    x0 = case["coarse_centroids"][3:4].copy()
-    assert np.array_equal(g.encode_preassigned(x0, np.array([3], np.int64)), zero)   # x - c = 0  ==  key < 0
+    assert np.array_equal(c2[same], codes[same]) and (c2[~same] != codes[~same]).any()
+    # a vector encoded for the "wrong" list = that list's own encoding of the vector: the oracle's encode of
+    # x - c[a2] + c[a'] ... is checked directly instead: residual to list a2, PQ argmin per sub-quantizer
+    cent, pq = case["coarse_centroids"], case["pq_centroids"].reshape(case.M, 1 << case.nbits, -1)
+    for i in (7, 14, 700):
+        r = (x[i] - cent[a2[i]]).reshape(case.M, -1)
+        ref = [int(np.argmin(((pq[m] - r[m]) ** 2).sum(1))) for m in range(case.M)]
+        assert (np.asarray(ref) == c2[i]).mean() >= 0.9          # float32 vs numpy summation order: near-ties may differ
+    # key < 0  ==  zero residual  ==  a vector sitting on its centroid
+    zero = g.encode_preassigned(cent[3:4].copy(), np.array([3], np.int64))
+    assert np.array_equal(c2[5], zero[0])
