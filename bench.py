@@ -324,6 +324,56 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
                                             pq.cpu().numpy(), lam, ei, ed, fp16=fp16)
         out[name] = {"value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
                      "self_hit_in_top_k": sk, "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"]}
+    # the same geometry at the reference driver's DATABASE size: 238 codes on every one of the 4.19 M lines
+    # (998 M codes), loaded as uniformly random (code, lambda) bytes -- the byte traffic of the populated 1 B-vector
+    # index without its 150 s device-side build (recall is meaningless here; the oracle check on the device's own
+    # lines is not).  This is the leg with a roofline: SURVEY.md 8(d) prices the VLQ scan at 17 B per scanned code.
+    per = 238
+    nbig = per * nlist * nedge
+    codes = torch.empty((nbig, M), dtype=torch.uint8, device=dev)
+    for i in range(0, nbig, 1 << 26):
+        codes[i:i + (1 << 26)] = torch.randint(0, 256, (min(1 << 26, nbig - i), M), dtype=torch.uint8, device=dev, generator=gen)
+    lams = torch.randint(0, 256, (nbig,), dtype=torch.uint8, device=dev, generator=gen)
+    g.set_lists(codes, lams, torch.arange(nbig, dtype=torch.int64, device=dev),
+                torch.arange(nlist * nedge + 1, dtype=torch.int64, device=dev) * per)
+    del codes, lams
+    peak = 8000.0
+    # bytes from the fabric per scan launch, rocprofv3 --pmc FETCH_SIZE x 2 (profiles/r03_pmc_vlq.txt), quoted only for
+    # the workload and kernels it was measured on
+    pmc_traffic = {"fp32_tables": 44.8e9, "float16_tables": 26.0e9}
+    for name, fp16 in (("fp32_tables", False), ("float16_tables", True)):
+        g.set_float16_tables(fp16)
+        for _ in range(2):
+            g.search(xq, nprobe, w1, k, D=D, I=I)
+        torch.cuda.synchronize()
+        g.stats(reset=True)
+        g.profile(True)
+        g.profile_read(reset=True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.search(xq, nprobe, w1, k, D=D, I=I)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        scan_ms, launches = g.profile_read(reset=True)
+        g.profile(False)
+        kernel_ms = scan_ms / max(1, launches)
+        ncode = g.stats(reset=True) / reps
+        chk = scale_checks.check_vlq_sample(g, xq[np.r_[0:2, nq // 2:nq // 2 + 2]].cpu().numpy(), nprobe, w1, k, cent.cpu().numpy(),
+                                            pq.cpu().numpy(), lam, ei, ed, fp16=fp16)
+        achieved = ncode * (M + 1) / (kernel_ms * 1e-3) / 1e9
+        traffic = pmc_traffic[name] if nq == 2000 else None
+        out["codes_1b_" + name] = {
+            "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
+            "database": "%d synthetic 17-byte codes, %d per line" % (nbig, per),
+            "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"],
+            "roofline": {"bound": "hbm", "kernel": "line16h_scan_kernel" if fp16 else "line16_scan_kernel", "kernel_ms": kernel_ms,
+                         "launches": launches, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "algorithmic_bytes": ncode * (M + 1), "traffic": traffic,
+                         "frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / peak) if traffic else None,
+                         "note": "achieved = scanned codes x 17 B / scan-kernel time (HIP events on the index's stream); the "
+                                 "kernel also reads one table row per kept line (%d KB x %d lines per query) -- the reference's "
+                                 "kernel reads two -- which is what `traffic` (PMC FETCH_SIZE x 2) shows and what bounds it"
+                                 % (8 if fp16 else 16, w1)}}
     return out
 
 

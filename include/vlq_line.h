@@ -71,6 +71,11 @@ int vlq_line_get_list(vlq_line_t h, int64_t line, uint8_t* codes_out, uint8_t* l
 int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1, int k, float* D,
                     int64_t* I, int32_t* lines_out);
 int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset);
+/* Scan-kernel time of the searches since the last reset, measured with HIP events recorded on the index's stream
+ * around every scan launch (what bench.py prices against the roofline; the role of the reference's KernelTimer,
+ * gpu/utils/Timer.h:19-54).  enable: 0 off, 1 on.  *scan_ms = sum over launches, *launches = their number. */
+int vlq_line_profile(vlq_line_t h, int enable);
+int vlq_line_profile_read(vlq_line_t h, double* scan_ms, int64_t* launches, int reset);
 
 /* GpuIndexIVFPQConfig::useFloat16LookupTables (gpu/GpuIndexIVFPQ.h:24-38) for the VLQ search -- what the
  * reference's VLQ drivers run with (gpu/test/deep1b16_query.cpp:239-243).  As in the reference: term 2 and

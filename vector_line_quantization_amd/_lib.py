@@ -24,7 +24,7 @@ SYMBOLS = [
     "vlq_line_set_pq_centroids", "vlq_line_set_lambda_codebook", "vlq_line_set_graph",
     "vlq_line_build_graph", "vlq_line_assign", "vlq_line_residuals", "vlq_line_encode", "vlq_line_add",
     "vlq_line_set_lists", "vlq_line_ntotal", "vlq_line_list_length", "vlq_line_get_list",
-    "vlq_line_search", "vlq_line_stats",
+    "vlq_line_search", "vlq_line_stats", "vlq_line_profile", "vlq_line_profile_read",
 ]
 
 

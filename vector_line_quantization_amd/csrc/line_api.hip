@@ -14,6 +14,12 @@ struct vlq_line_s {
     bool have_graph = false, have_lambda = false;
     // float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables): half(term2), built on demand
     bool fp16_tables = false, term2h_valid = false;
+    // scan-kernel timing (vlq_line_profile): event pairs recorded around the scan launches, drained on read
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms = 0;
+    int64_t prof_calls = 0;
     int row_mode = 0;                    // vlq_line_set_row_mode: 0 auto, 1 stored term-2 rows, 2 rebuilt rows
     DevBuf term2h, ws_qtabh;
     std::vector<int64_t> h_line_off, h_line_len;
@@ -126,6 +132,8 @@ void vlq_line_destroy(vlq_line_t h) {
                       &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_sel_meta, &h->ws_sel_cnt, &h->ws_x, &h->ws_D,
                       &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats, &h->term2h, &h->ws_qtabh};
     for (auto b : bufs) b->release();
+    for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->base) vlq_ivfpq_destroy(h->base);
     delete h;
 }
@@ -439,6 +447,12 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.ncode = h->stats.as<unsigned long long>();
         a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;
         a.max_line_codes = VLQ_LINE_MAX_CODES;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->prof) {
+            auto get = [&]() { hipEvent_t e = nullptr; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr; return e; };
+            ev0 = get(); ev1 = get();
+            if (ev0 && ev1) (void)hipEventRecord(ev0, b->stream);
+        }
         if (rebuilt_rows) {
             a.coarse = b->coarse.as<float>(); a.pq_cent = b->pq.as<float>(); a.pq_rnorm = b->rnorm.as<float>();
             a.term2 = nullptr;
@@ -446,11 +460,37 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         } else {
             vlq::launch_line_scan(a, b->stream);
         }
+        if (ev0 && ev1) { (void)hipEventRecord(ev1, b->stream); h->prof_pending.push_back({ev0, ev1}); }
         HIP_TRY(hipGetLastError());
     }
     if (lines_out) HIP_TRY(hipMemcpyAsync(lines_out, h->ws_sel_line.p, (size_t)n * w1 * 4, hipMemcpyDeviceToHost, b->stream));
     TRY(finish_outputs(b, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
     if (lines_out) HIP_TRY(hipStreamSynchronize(b->stream));
+    return VLQ_OK;
+}
+
+int vlq_line_profile(vlq_line_t h, int enable) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    h->prof = enable != 0;
+    return VLQ_OK;
+}
+
+int vlq_line_profile_read(vlq_line_t h, double* scan_ms, int64_t* launches, int reset) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h->base));
+    for (auto& p : h->prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            h->prof_ms += ms;
+            h->prof_calls++;
+        }
+        h->prof_pool.push_back(p.first);
+        h->prof_pool.push_back(p.second);
+    }
+    h->prof_pending.clear();
+    if (scan_ms) *scan_ms = h->prof_ms;
+    if (launches) *launches = h->prof_calls;
+    if (reset) { h->prof_ms = 0; h->prof_calls = 0; }
     return VLQ_OK;
 }
 

@@ -350,3 +350,12 @@ class GpuVLQ:
         nc = C.c_uint64()
         check(lib().vlq_line_stats(self._h, C.byref(nc), C.c_int(int(reset))))
         return nc.value
+
+    def profile(self, enable=True):
+        check(lib().vlq_line_profile(self._h, C.c_int(int(enable))))
+
+    def profile_read(self, reset=True):
+        """(scan-kernel milliseconds summed over the launches since the last reset, number of launches)"""
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().vlq_line_profile_read(self._h, C.byref(ms), C.byref(n), C.c_int(int(reset))))
+        return ms.value, n.value
