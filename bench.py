@@ -674,6 +674,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "vlq::scan16_kernel", "kernel_ms": scan_ms,
+                     # `achieved` / `frac` are ALGORITHMIC code bytes over kernel time: an effective rate,
+                     # part of it served by L2 / Infinity Cache.  frac_measured = bytes the fabric counters saw over the
+                     # same time (null when no counter run matches this build and workload).
+                     "frac_measured": (traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and scan_ms > 0) else None,
                      "algorithmic_bytes": code_bytes,
                      "lut_bytes_separate": lut_bytes,
                      "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0},
