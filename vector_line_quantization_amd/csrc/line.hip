@@ -520,44 +520,37 @@ void launch_to_half(const float* in, int64_t n, float scale, uint16_t* out, hipS
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, scale, out);
 }
 
-// T23h at LDS byte 0, T4h at byte 8192: one SDWA op makes code byte * 2, both 16-bit reads use it
-#define VLQ_H16_BLOCK(W0, W1, O)                                                                   \
+// One table of 4096 dwords at LDS byte 0: entry (m, j) = {T23h[m][j] (low half), T4h[m][j] (high half)}.  One SDWA
+// op makes code byte * 4 and ONE ds_read_b32 per code byte serves both look-ups (two ds_read_u16 before: the LDS
+// gather rate, not the 8 KB rows, was what held this kernel at 4.9 TB/s of fabric reads, profiles/r03_pmc_vlq.txt).
+#define VLQ_HP_BLOCK(W0, W1, O)                                                                   \
     asm volatile(                                                                          \
-        "v_lshlrev_b32_sdwa %0, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-        "v_lshlrev_b32_sdwa %1, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-        "v_lshlrev_b32_sdwa %2, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
-        "v_lshlrev_b32_sdwa %3, %18, %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
-        "v_lshlrev_b32_sdwa %4, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-        "v_lshlrev_b32_sdwa %5, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-        "v_lshlrev_b32_sdwa %6, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
-        "v_lshlrev_b32_sdwa %7, %18, %17 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
-        "ds_read_u16 %8, %0 offset:8192+" #O "+0\n\t" \
-        "ds_read_u16 %0, %0 offset:" #O "+0\n\t" \
-        "ds_read_u16 %9, %1 offset:8192+" #O "+512\n\t" \
-        "ds_read_u16 %1, %1 offset:" #O "+512\n\t" \
-        "ds_read_u16 %10, %2 offset:8192+" #O "+1024\n\t" \
-        "ds_read_u16 %2, %2 offset:" #O "+1024\n\t" \
-        "ds_read_u16 %11, %3 offset:8192+" #O "+1536\n\t" \
-        "ds_read_u16 %3, %3 offset:" #O "+1536\n\t" \
-        "ds_read_u16 %12, %4 offset:8192+" #O "+2048\n\t" \
-        "ds_read_u16 %4, %4 offset:" #O "+2048\n\t" \
-        "ds_read_u16 %13, %5 offset:8192+" #O "+2560\n\t" \
-        "ds_read_u16 %5, %5 offset:" #O "+2560\n\t" \
-        "ds_read_u16 %14, %6 offset:8192+" #O "+3072\n\t" \
-        "ds_read_u16 %6, %6 offset:" #O "+3072\n\t" \
-        "ds_read_u16 %15, %7 offset:8192+" #O "+3584\n\t" \
-        "ds_read_u16 %7, %7 offset:" #O "+3584\n\t" \
+        "v_lshlrev_b32_sdwa %0, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %10, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "v_lshlrev_b32_sdwa %4, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %5, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %6, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %7, %10, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:" #O "+0\n\t" \
+        "ds_read_b32 %1, %1 offset:" #O "+1024\n\t" \
+        "ds_read_b32 %2, %2 offset:" #O "+2048\n\t" \
+        "ds_read_b32 %3, %3 offset:" #O "+3072\n\t" \
+        "ds_read_b32 %4, %4 offset:" #O "+4096\n\t" \
+        "ds_read_b32 %5, %5 offset:" #O "+5120\n\t" \
+        "ds_read_b32 %6, %6 offset:" #O "+6144\n\t" \
+        "ds_read_b32 %7, %7 offset:" #O "+7168\n\t" \
         "s_waitcnt lgkmcnt(0)"                                                                                 \
-        : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]), "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7])                                                                               \
-        : "v"(W0), "v"(W1), "v"(one)                                                       \
+        : "=&v"(vp[0]), "=&v"(vp[1]), "=&v"(vp[2]), "=&v"(vp[3]), "=&v"(vp[4]), "=&v"(vp[5]), "=&v"(vp[6]), "=&v"(vp[7]) \
+        : "v"(W0), "v"(W1), "v"(two)                                                       \
         : "memory")
 
 template <int KPL>
-__global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(LineScanArgs a, int queue_off) {
+__global__ __launch_bounds__(256, KPL <= 4 ? 5 : 2) void line16h_scan_kernel(LineScanArgs a, int queue_off) {
     constexpr int E = 4096, NT = 256, NI = 2;       // a row of 4096 halves = 512 x 16 bytes: two per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-    uint4* t23 = reinterpret_cast<uint4*>(smraw);                    // [E] halves at LDS byte 0
-    uint4* t4 = reinterpret_cast<uint4*>(smraw + 8192);              // [E] halves at LDS byte 8192
+    uint4* tab = reinterpret_cast<uint4*>(smraw);                    // [E] dwords {T23h, T4h} at LDS byte 0
     float* lamtab = reinterpret_cast<float*>(smraw + 16384);         // [256]
     u64* queue = reinterpret_cast<u64*>(smraw + queue_off);          // [4][64]
     uint32_t* cum = reinterpret_cast<uint32_t*>(queue + 4 * 64);     // [w1+1] scan position of the rank-th line
@@ -566,8 +559,8 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(Lin
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if (__builtin_amdgcn_groupstaticsize() != 0) return;             // the table offsets above are absolute
-    uint32_t one = 1;
-    asm volatile("" : "+v"(one));
+    uint32_t two = 2;
+    asm volatile("" : "+v"(two));
     const int64_t q = blockIdx.x;
     const int cnt = a.sel_cnt[q];
     const uint4* mq = reinterpret_cast<const uint4*>(a.sel_meta + q * a.w1);   // 3 x 16 bytes per record
@@ -582,69 +575,83 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(Lin
     WaveSelect<KPL> sel;
     sel.init(a.k, queue + wave * 64, lane);
 
-    H8 t2c[NI], ts[NI];
+    H8 t2c[NI], t23[NI], ts[NI];              // anchor row, T23h, far-end row of the next line
     uint4 c0 = make_uint4(0, 0, 0, 0);
     uint32_t l0 = 0;
-    auto prefetch = [&](const uint4 m0, const uint4 m1) __attribute__((always_inline)) {
-        const int64_t off = (int64_t)(((uint64_t)m0.y << 32) | m0.x);
-        const uint32_t len = m0.z;
-        const int32_t s = (int32_t)m1.x;
+    // a line record is 12 dwords: lane l < 12 holds dword l, fields are read with v_readlane (2 registers for two
+    // records instead of 24).  A second row in flight per workgroup (rows requested two lines ahead) was measured
+    // and is slower, as it is with fp32 tables: 5.54 against 5.24 ms at the C5 geometry.
+    const uint32_t* mqw = reinterpret_cast<const uint32_t*>(mq);
+    const int fl = lane < 12 ? lane : 0;
+    auto rec_off = [&](uint32_t rec) __attribute__((always_inline)) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(rec, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(rec, 0));
+    };
+    auto load_row = [&](uint32_t rec, H8 (&dst)[NI]) __attribute__((always_inline)) {
+        const int32_t s = __builtin_amdgcn_readlane(rec, 4);
         const uint4* src = reinterpret_cast<const uint4*>(a.term2h + (size_t)s * E);
 #pragma unroll
-        for (int i = 0; i < NI; i++) ts[i].u = src[i * NT + t];
+        for (int i = 0; i < NI; i++) dst[i].u = src[i * NT + t];
+    };
+    auto load_codes = [&](uint32_t rec) __attribute__((always_inline)) {
+        const int64_t off = rec_off(rec);
+        const uint32_t len = __builtin_amdgcn_readlane(rec, 2);
         const uint32_t j = min((uint32_t)t, len - 1);
         c0 = reinterpret_cast<const uint4*>(a.codes)[off + j];
         l0 = a.lambdas[off + j];
     };
-    uint4 ma0 = make_uint4(0, 0, 0, 0), ma1 = ma0, ma2 = ma0, mb0 = ma0, mb1 = ma0, mb2 = ma0;
+    uint32_t mcur = 0, mnext = 0;
     if (cnt > 0) {
-        ma0 = mq[0]; ma1 = mq[1]; ma2 = mq[2];
-        const int w1c = min(1, cnt - 1);
-        mb0 = mq[3 * w1c]; mb1 = mq[3 * w1c + 1]; mb2 = mq[3 * w1c + 2];
-        prefetch(ma0, ma1);
+        mcur = mqw[fl];
+        mnext = mqw[12 * min(1, cnt - 1) + fl];
+        load_row(mcur, ts);
+        load_codes(mcur);
     }
     int cprev = -1;
     uint32_t total = 0;
     for (int w = 0; w < cnt; w++) {
-        const int64_t off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane(ma0.y) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readfirstlane(ma0.x));
-        const uint32_t len = __builtin_amdgcn_readfirstlane(ma0.z);
-        const int line = __builtin_amdgcn_readfirstlane(ma0.w);
-        const float c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.y));
-        const float b2 = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.z));
-        const float g = __uint_as_float(__builtin_amdgcn_readfirstlane(ma1.w));
-        const uint32_t pos0 = __builtin_amdgcn_readfirstlane(ma2.x);
-        const int rank = __builtin_amdgcn_readfirstlane(ma2.y);
+        const int64_t off = rec_off(mcur);
+        const uint32_t len = __builtin_amdgcn_readlane(mcur, 2);
+        const int line = __builtin_amdgcn_readlane(mcur, 3);
+        const float c2 = __uint_as_float(__builtin_amdgcn_readlane(mcur, 5));
+        const float b2 = __uint_as_float(__builtin_amdgcn_readlane(mcur, 6));
+        const float g = __uint_as_float(__builtin_amdgcn_readlane(mcur, 7));
+        const uint32_t pos0 = __builtin_amdgcn_readlane(mcur, 8);
+        const int rank = __builtin_amdgcn_readlane(mcur, 9);
         const int c = line / a.nedge;
         if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
-        __syncthreads();                         // previous line fully scanned
-        if (c != cprev) {                        // new anchor: its half row into registers, T23h into LDS
+        if (c != cprev) {                        // new anchor: its half row and T23h = hadd(term2h[c], term3h) in registers
             const uint4* src = reinterpret_cast<const uint4*>(a.term2h + (size_t)c * E);
 #pragma unroll
             for (int i = 0; i < NI; i++) t2c[i].u = src[i * NT + t];
 #pragma unroll
-            for (int i = 0; i < NI; i++) {
-                H8 v;
+            for (int i = 0; i < NI; i++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) v.h[e] = t2c[i].h[e] + q3[i].h[e];      // half add, round to nearest even
-                t23[i * NT + t] = v.u;
-            }
+                for (int e = 0; e < 4; e++) t23[i].h[e] = t2c[i].h[e] + q3[i].h[e];    // half add, round to nearest even
             cprev = c;
         }
+        __syncthreads();                         // previous line fully scanned
 #pragma unroll
         for (int i = 0; i < NI; i++) {
-            H8 v;
+            H8 t4;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v.h[e] = ts[i].h[e] - t2c[i].h[e];          // half subtract
-            t4[i * NT + t] = v.u;
+            for (int e = 0; e < 4; e++) t4.h[e] = ts[i].h[e] - t2c[i].h[e];            // half subtract
+            // entries 8*(i*256+t) .. +7 as dwords {T23h, T4h}: two 16-byte stores
+            const uint4 a23 = t23[i].u, a4 = t4.u;
+            uint4 lo, hi;
+            lo.x = __builtin_amdgcn_perm(a4.x, a23.x, 0x05040100u); lo.y = __builtin_amdgcn_perm(a4.x, a23.x, 0x07060302u);
+            lo.z = __builtin_amdgcn_perm(a4.y, a23.y, 0x05040100u); lo.w = __builtin_amdgcn_perm(a4.y, a23.y, 0x07060302u);
+            hi.x = __builtin_amdgcn_perm(a4.z, a23.z, 0x05040100u); hi.y = __builtin_amdgcn_perm(a4.z, a23.z, 0x07060302u);
+            hi.z = __builtin_amdgcn_perm(a4.w, a23.w, 0x05040100u); hi.w = __builtin_amdgcn_perm(a4.w, a23.w, 0x07060302u);
+            tab[2 * (i * NT + t)] = lo;
+            tab[2 * (i * NT + t) + 1] = hi;
         }
         uint4 cc = c0;
         uint32_t lb = l0;
-        ma0 = mb0; ma1 = mb1; ma2 = mb2;
+        mcur = mnext;
         if (w + 1 < cnt) {
-            prefetch(ma0, ma1);
-            const int w2 = min(w + 2, cnt - 1);
-            mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
+            load_row(mcur, ts);
+            load_codes(mcur);
+            mnext = mqw[12 * min(w + 2, cnt - 1) + fl];
         }
         __syncthreads();
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
@@ -657,18 +664,19 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16h_scan_kernel(Lin
             const float l = lamtab[lb];
             float dist = __fadd_rn(__fadd_rn(b2, __fmul_rn(l, g)), __fmul_rn(__fsub_rn(__fmul_rn(l, l), l), c2));
             float tmp = 0.f;
-            auto h2f = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)v); };
+            auto lo2f = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v & 0xffffu)); };
+            auto hi2f = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16)); };
             {
-                uint32_t va[8], vb[8];
-                VLQ_H16_BLOCK(cc.x, cc.y, 0);
+                uint32_t vp[8];
+                VLQ_HP_BLOCK(cc.x, cc.y, 0);
 #pragma unroll
-                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, h2f(va[m])); tmp = __fadd_rn(tmp, h2f(vb[m])); }
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, lo2f(vp[m])); tmp = __fadd_rn(tmp, hi2f(vp[m])); }
             }
             {
-                uint32_t va[8], vb[8];
-                VLQ_H16_BLOCK(cc.z, cc.w, 4096);
+                uint32_t vp[8];
+                VLQ_HP_BLOCK(cc.z, cc.w, 8192);
 #pragma unroll
-                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, h2f(va[m])); tmp = __fadd_rn(tmp, h2f(vb[m])); }
+                for (int m = 0; m < 8; m++) { dist = __fadd_rn(dist, lo2f(vp[m])); tmp = __fadd_rn(tmp, hi2f(vp[m])); }
             }
             dist = __fadd_rn(dist, __fmul_rn(l, tmp));
             sel.template offer<false>(dist, pos0 + j, j < len);
