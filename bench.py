@@ -726,6 +726,22 @@ def main():
             out["host_buffers"] = {"ms_per_step": dth * 1e3, "ratio_to_device_resident": dth * 1e3 / out["ms_per_step"],
                                    "results_equal_device_resident": bool(np.array_equal(Dh, D_h) and np.array_equal(Ih, I_h)),
                                    "note": "same batch, x / D / I in pageable host memory (numpy), synchronous call"}
+            # the same call with the three arrays in PAGE-LOCKED host memory (what GpuResources::getPinnedMemory hands
+            # a driver, gpu/GpuResources.h:40): the copies are asynchronous, the kernels queue up behind them
+            xp = torch.from_numpy(xq_h).pin_memory()
+            Dp = torch.empty((xq_h.shape[0], args.k), dtype=torch.float32).pin_memory()
+            Ip = torch.empty((xq_h.shape[0], args.k), dtype=torch.int64).pin_memory()
+            xpn, Dpn, Ipn = xp.numpy(), Dp.numpy(), Ip.numpy()
+            for _ in range(3):
+                g.search(xpn, args.nprobe, args.k, D=Dpn, I=Ipn)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                g.search(xpn, args.nprobe, args.k, D=Dpn, I=Ipn)
+            dtp = (time.perf_counter() - t1) / 10
+            out["host_buffers_pinned"] = {"ms_per_step": dtp * 1e3, "ratio_to_device_resident": dtp * 1e3 / out["ms_per_step"],
+                                          "value": xq_h.shape[0] / dtp,
+                                          "results_equal_device_resident": bool(np.array_equal(Dpn, D_h) and np.array_equal(Ipn, I_h)),
+                                          "note": "same batch, x / D / I in page-locked host memory, synchronous call"}
             g.stats(reset=True)
         if world == 1 and default_workload and not fdir and not args.no_second_dataset:
             out["second_dataset"] = second_dataset(torch, args, dev)

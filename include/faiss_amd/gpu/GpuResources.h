@@ -2,7 +2,11 @@
 // gpu/StandardGpuResources.h:23-84).  The reference hands out cuBLAS handles, a
 // scratch stack (30 % of device memory) and pinned memory; the MI355X library owns
 // its workspace (sized on demand out of 288 GB of HBM3E) and needs only streams, so
-// the temp/pinned-memory setters are accepted and recorded but allocate nothing.
+// the temp-memory setters are accepted and recorded but allocate nothing.  Pinned memory
+// is real: getPinnedMemory() hands out one page-locked block (256 MB unless setPinnedMemory
+// said otherwise, StandardGpuResources.cpp:24), allocated on first use.  A caller that keeps
+// its queries and result arrays there gets truly asynchronous copies: the library's kernels
+// are enqueued behind the copy instead of after it (a pageable hipMemcpyAsync blocks the host).
 #pragma once
 #include <cstddef>
 #include <map>
@@ -27,14 +31,19 @@ class GpuResources {
 
 class StandardGpuResources : public GpuResources {
  public:
-  StandardGpuResources() : tempMemSize_(0), pinnedSize_(0) {}
+  StandardGpuResources() : tempMemSize_(0), pinnedSize_((size_t)256 << 20), pinned_(nullptr) {}
   ~StandardGpuResources() override {
     for (auto& kv : streams_) for (auto s : kv.second) (void)hipStreamDestroy(s);
+    if (pinned_) (void)hipHostFree(pinned_);
   }
   void noTempMemory() { tempMemSize_ = 0; }
   void setTempMemory(size_t size) { tempMemSize_ = size; }
   void setTempMemoryFraction(float) {}
-  void setPinnedMemory(size_t size) { pinnedSize_ = size; }
+  /// StandardGpuResources.cpp:60-67: only before the block exists
+  void setPinnedMemory(size_t size) {
+    FAISS_THROW_IF_NOT_MSG(!pinned_, "pinned memory already allocated");
+    pinnedSize_ = size;
+  }
 
   void initializeForDevice(int device) override {
     if (streams_.count(device)) return;
@@ -53,11 +62,21 @@ class StandardGpuResources : public GpuResources {
     return {streams_[device][1], streams_[device][2]};
   }
   hipStream_t getAsyncCopyStream(int device) override { initializeForDevice(device); return streams_[device][3]; }
-  std::pair<void*, size_t> getPinnedMemory() override { return {nullptr, 0}; }
+  std::pair<void*, size_t> getPinnedMemory() override {
+    if (!pinned_ && pinnedSize_ > 0) {
+      if (hipHostMalloc(&pinned_, pinnedSize_, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        pinned_ = nullptr;
+        FAISS_THROW_FMT("hipHostMalloc(%zu) failed", pinnedSize_);
+      }
+    }
+    return {pinned_, pinned_ ? pinnedSize_ : 0};
+  }
 
  private:
   std::map<int, std::vector<hipStream_t> > streams_;
   size_t tempMemSize_, pinnedSize_;
+  void* pinned_;
 };
 
 } }

@@ -244,6 +244,26 @@ int main() {
     printf("part 2f: IndexProxy over 1 and 2 GPU replicas answers like one index\n");
   }
 
+  // part 2g: GpuResources::getPinnedMemory (gpu/GpuResources.h:40, StandardGpuResources.cpp:24: one 256 MB
+  // page-locked block): queries and results placed there take the asynchronous copy path and return the same rows
+  {
+    faiss::gpu::StandardGpuResources pres;
+    std::pair<void*, size_t> pin = pres.getPinnedMemory();
+    EXPECT(pin.first != nullptr && pin.second == ((size_t)256 << 20));
+    EXPECT(pres.getPinnedMemory().first == pin.first);              // one block, handed out again
+    hipPointerAttribute_t attr;
+    EXPECT(hipPointerGetAttributes(&attr, pin.first) == hipSuccess && attr.type == hipMemoryTypeHost);
+    float* pq = (float*)pin.first;
+    float* pD = pq + (size_t)nq * d;
+    faiss::Index::idx_t* pI = (faiss::Index::idx_t*)(pD + (size_t)nq * k);
+    std::copy(queries.begin(), queries.end(), pq);
+    faiss::gpu::GpuIndexIVFPQ gp(&pres, &index);
+    gp.setNumProbes(5);
+    gp.search(nq, pq, k, pD, pI);
+    EXPECT(std::equal(nns.begin(), nns.end(), pI) && std::equal(dis.begin(), dis.end(), pD));
+    printf("part 2g: %zu MB of pinned memory from GpuResources; search from / into it equals the pageable call\n", pin.second >> 20);
+  }
+
   // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of
   // tests/sift1b_imi_pq.cpp:225-236): quantizer_trains_alone, table type 2
   {
