@@ -4,8 +4,8 @@
 // What the MI355X library does with them:
 //   indicesOptions            ids always live in HBM as 64-bit values; INDICES_IVF is honoured (pairs)
 //   useFloat16CoarseQuantizer accepted, computed in fp32 (superset precision; see GpuIndexIVFPQ.h)
-//   useFloat16                VLQ index (16 x 8-bit codes): float16 look-up tables, built as the reference builds
-//                             them (vlq_line_set_float16_tables); plain IVFPQ: see GpuIndexIVFPQ.h
+//   useFloat16                16 x 8-bit codes: float16 look-up tables, built as the reference builds them
+//                             (vlq_line_set_float16_tables / vlq_ivfpq_set_float16_tables); other shapes: fp32
 //   usePrecomputed            honoured (table mode 1)
 //   reserveVecs               honoured (reserveMemory)
 //   storeTransposed           layout hint of the reference's cuBLAS call: no effect

@@ -185,7 +185,7 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, enable ? 1 : 0, 0));
   }
   bool getPrecomputedCodes() const { return usePrecomputed_; }
-  /// what the caller asked for (honoured by the VLQ search with 16 x 8-bit codes; see verifyConfig_)
+  /// what the caller asked for (honoured for 16 x 8-bit codes, plain and VLQ; other shapes compute in fp32)
   bool getFloat16LookupTables() const { return ivfpqConfig_.useFloat16LookupTables; }
   int getNumSubQuantizers() const { return subQuantizers_; }
   int getBitsPerCode() const { return bitsPerCode_; }
@@ -438,6 +438,10 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_ivfpq_set_stream(h_, (void*)resources_->getDefaultStream(device_)));
     usePrecomputed_ = ivfpqConfig_.usePrecomputedTables;
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, usePrecomputed_ ? 1 : 0, 0));
+    // useFloat16LookupTables: half tables for 16 x 8-bit codes with precomputed tables, built as the reference
+    // builds them (vlq_ivfpq_set_float16_tables); other shapes compute in fp32 (superset precision)
+    if (ivfpqConfig_.useFloat16LookupTables && subQuantizers_ == 16 && bitsPerCode_ == 8)
+      VLQ_CHECK(vlq_ivfpq_set_float16_tables(h_, 1));
   }
   GpuIndexIVFPQConfig ivfpqConfig_;
   int nlist_, nprobe_, subQuantizers_, bitsPerCode_;

@@ -117,6 +117,17 @@ int64_t vlq_ivfpq_ntotal(vlq_ivfpq_t h);
 int vlq_ivfpq_list_length(vlq_ivfpq_t h, int list_id, int64_t* len);
 int vlq_ivfpq_get_list(vlq_ivfpq_t h, int list_id, uint8_t* codes_out, int64_t* ids_out);
 
+/* GpuIndexIVFPQConfig::useFloat16LookupTables (gpu/GpuIndexIVFPQ.h:24-38) for the plain IVFPQ search, M = 16 x 8
+ * bit in table mode 1, k <= 256 (other shapes and larger k keep fp32 tables).  As in the reference's kernel
+ * (gpu/impl/PQScanMultiPassPrecomputed.cu:30-114,375-477 with LookupT = half): term 2 and term 3 are kept as half
+ * (impl/IVFPQ.cu:599-684, :1599-1680), a list's table is their half sum, looked-up entries are added in float.
+ * Off by default: the fp32 tables are the parity build against the CPU library; with half tables the
+ * reference's own GPU-vs-CPU bar applies (gpu/test/TestGpuIndexIVFPQ.cpp:89-99: relative distance error
+ * <= 0.015, <= 30 % of the results differing in fp16 mode).  The search returns VLQ_ERR_UNSUPPORTED when a
+ * term-2 entry lies outside the half range (|value| > 65504: byte-valued data such as SIFT; fine for
+ * normalised descriptors) -- the reference would silently hold infinities there. */
+int vlq_ivfpq_set_float16_tables(vlq_ivfpq_t h, int enable);
+
 /* Scheduling of the 16-byte-code scan kernel -- SPEED ONLY, results are identical in every mode:
  *   0  automatic: query-major today -- the list-owned schedule moves fewer bytes but is slower on every data
  *      set measured, so nothing selects it by itself

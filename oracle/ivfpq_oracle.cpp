@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <immintrin.h>
 #include <vector>
 
 #ifdef _OPENMP
@@ -46,7 +47,7 @@ struct orc_index {
     int32_t ksub, dsub, code_size;
     int32_t by_residual;            // IndexIVFPQ.h:30
     int32_t use_precomputed_table;  // IndexIVFPQ.h:31 (0 or 1; 2 = IMI not restated)
-    int32_t _pad;
+    int32_t float16_tables;         // != 0: GpuIndexIVFPQConfig::useFloat16LookupTables for the table-1 scan (below)
     int64_t max_codes;              // IndexIVFPQ.h:40 (0 = unlimited)
     const float* coarse_centroids;  // [nlist][d]   IndexFlat::xb
     const float* pq_centroids;      // [M][ksub][dsub] ProductQuantizer.h:51-60
@@ -505,6 +506,19 @@ int64_t orc_search_knn_with_key(const orc_index* ix, size_t nx, const float* qx,
                             fvec_madd((size_t)Mf * ix->ksub,
                                       ix->precomputed_table + ((size_t)ki * ix->M + (size_t)cm * Mf) * ix->ksub,
                                       -2.0f, sim_table_2.data() + o, sim_table.data() + o);
+                        }
+                    } else if (ix->float16_tables) {
+                        // useFloat16LookupTables on the plain IVFPQ path, as the reference's GPU kernel forms the
+                        // table (gpu/impl/PQScanMultiPassPrecomputed.cu:30-114 loadPrecomputedTerm with LookupT = half):
+                        // term 2 and term 3 are kept as half (impl/IVFPQ.cu:599-684 / :1599-1680 toHalf), the table is
+                        // their HALF sum, and the looked-up entries are accumulated in float (:431-449 ConvertTo<float>)
+                        dis0 = cdi[ik];
+                        const float* t2 = ix->precomputed_table + (size_t)key * mk;
+                        for (size_t e = 0; e < mk; e++) {
+                            const uint16_t h2 = (uint16_t)_cvtss_sh(t2[e], _MM_FROUND_TO_NEAREST_INT);
+                            const uint16_t h3 = (uint16_t)_cvtss_sh(-2.0f * sim_table_2[e], _MM_FROUND_TO_NEAREST_INT);
+                            // IEEE half add = the float sum of two halves rounded once more (24 >= 2*11 + 2 bits)
+                            sim_table[e] = _cvtsh_ss((uint16_t)_cvtss_sh(_cvtsh_ss(h2) + _cvtsh_ss(h3), _MM_FROUND_TO_NEAREST_INT));
                         }
                     } else {
                         dis0 = cdi[ik];

@@ -17,7 +17,7 @@ class _OrcIndex(C.Structure):
     _fields_ = [
         ("d", C.c_int32), ("nlist", C.c_int32), ("M", C.c_int32), ("nbits", C.c_int32),
         ("ksub", C.c_int32), ("dsub", C.c_int32), ("code_size", C.c_int32),
-        ("by_residual", C.c_int32), ("use_precomputed_table", C.c_int32), ("_pad", C.c_int32),
+        ("by_residual", C.c_int32), ("use_precomputed_table", C.c_int32), ("float16_tables", C.c_int32),
         ("max_codes", C.c_int64),
         ("coarse_centroids", C.c_void_p), ("pq_centroids", C.c_void_p),
         ("precomputed_table", C.c_void_p), ("codes", C.c_void_p), ("ids", C.c_void_p),
@@ -116,6 +116,7 @@ class OracleIndex:
         s.ksub, s.dsub, s.code_size = self.ksub, self.dsub, self.code_size
         s.by_residual = int(self.by_residual)
         s.use_precomputed_table = self.use_precomputed_table
+        s.float16_tables = int(getattr(self, "float16_tables", False))
         s.max_codes = self.max_codes
         s.coarse_centroids = _p(self.coarse_centroids)
         s.pq_centroids = _p(self.pq_centroids)

@@ -161,8 +161,8 @@ int main() {
   // tables requested through GpuClonerOptions, ids "on the CPU", a temp-memory fraction.  It must
   // construct, train, add and search.  The VLQ search then runs with float16 look-up tables (as the
   // reference does): its answers stay within the reference's own GPU-vs-CPU bar of the fp32 answers
-  // (relative distance error <= 0.015, gpu/test/TestGpuIndexIVFPQ.cpp:89-99); the plain IVFPQ index
-  // computes in fp32 whatever the flag says and answers exactly like the CPU index.
+  // (relative distance error <= 0.015, gpu/test/TestGpuIndexIVFPQ.cpp:89-99); so does the plain IVFPQ index
+  // (16 x 8-bit codes: half tables as well).
   {
     faiss::gpu::StandardGpuResources resources;
     resources.setTempMemoryFraction(0.25);
@@ -212,10 +212,20 @@ int main() {
     faiss::gpu::GpuIndexIVFPQ copy16(&resources, &index, cfg16);
     copy16.setNumProbes(5);
     copy16.search(nq, queries.data(), k, d16.data(), n16.data());
-    EXPECT(n16 == nns && d16 == dis);
+    {   // half tables on the plain path too (16 x 8-bit codes): the reference's GPU-vs-CPU bar against the fp32 answer
+        // (gpu/test/TestGpuIndexIVFPQ.cpp:89-99: relative distance error <= 0.015, few results differing)
+      int same = 0;
+      double worst = 0;
+      for (size_t i = 0; i < n16.size(); i++) {
+        same += n16[i] == nns[i];
+        if (n16[i] == nns[i]) worst = std::max(worst, std::fabs((double)d16[i] - dis[i]) / std::max(1e-6, (double)dis[i]));
+      }
+      printf("part 2e: plain IVFPQ, fp16 tables vs fp32: %d of %zu labels equal, max relative distance error %.2e\n", same, n16.size(), worst);
+      EXPECT(same >= (int)(0.9 * n16.size()) && worst <= 0.015 && d16 != dis);
+    }
     faiss::gpu::GpuMultipleClonerOptions mco;
     EXPECT(!mco.shard && mco.usePrecomputed);
-    printf("part 2e: reference driver configuration (useFloat16LookupTables, INDICES_CPU) accepted, answers equal fp32\n");
+    printf("part 2e: reference driver configuration (useFloat16LookupTables, INDICES_CPU) accepted\n");
   }
 
   // part 2f: faiss::gpu::IndexProxy (gpu/IndexProxy.cpp:123-168) over GPU replicas: one replica = the

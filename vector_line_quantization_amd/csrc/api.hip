@@ -2,6 +2,7 @@
 // device buffers, workspace, paging of large query batches, host<->device staging.
 // No CPU compute path exists here: every search/add entry point launches kernels.
 #include "handle.h"
+#include "line.h"
 #include "lists.h"
 
 namespace vlq_detail {
@@ -86,6 +87,29 @@ int ensure_term2(vlq_ivfpq_t h) {
                           h->dsub, h->rnorm.as<float>(), 2, h->term2.as<float>(), h->stream);
     HIP_TRY(hipGetLastError());
     h->term2_valid = true;
+    return VLQ_OK;
+}
+
+// half(term 2) for the float16 tables (impl/IVFPQ.cu:599-684 toHalf).  As in the reference the entries must fit
+// the half range: byte-valued (SIFT-like) data has |term 2| up to 1e5 and would turn into infinities -- refused.
+int ensure_term2h(vlq_ivfpq_t h) {
+    TRY(ensure_term2(h));
+    if (h->term2h_valid) return VLQ_OK;
+    const int64_t n = (int64_t)h->nlist * h->M * h->ksub;
+    TRY(h->ws_misc.reserve(16));
+    vlq::launch_max_abs(h->term2.as<float>(), n, h->ws_misc.as<unsigned int>(), h->stream);
+    unsigned int mx = 0;
+    HIP_TRY(hipMemcpyAsync(&mx, h->ws_misc.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float mxf;
+    memcpy(&mxf, &mx, 4);
+    if (!(mxf <= 65504.f))
+        return fail(VLQ_ERR_UNSUPPORTED, "float16 look-up tables: |term 2| reaches %g, beyond the half range (65504); "
+                    "use fp32 tables for this data (the reference's half tables would hold infinities)", (double)mxf);
+    TRY(h->term2h.reserve((size_t)n * 2));
+    vlq::launch_to_half(h->term2.as<float>(), n, 1.f, h->term2h.as<uint16_t>(), h->stream);
+    HIP_TRY(hipGetLastError());
+    h->term2h_valid = true;
     return VLQ_OK;
 }
 
@@ -305,6 +329,32 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.max_codes = h->max_codes;
         a.store_pairs = store_pairs;
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
+        if (h->fp16_tables && fast16 && h->imi_nbits == 0 && k <= 256) {
+            // useFloat16LookupTables: half(term 2) once per trained state, half(term 3) per page, half table sums
+            TRY(ensure_term2h(h));
+            TRY(h->ws_qtab.reserve((size_t)ni * E * sizeof(float)));
+            TRY(h->ws_qtabh.reserve((size_t)ni * E * 2));
+            {
+                StageTimer tq(h, 1);
+                vlq::launch_pq_tables(xi, ni, h->d, h->pq.as<float>(), h->M, h->ksub, h->dsub, nullptr, 0,
+                                      h->ws_qtab.as<float>(), h->stream);
+                vlq::launch_to_half(h->ws_qtab.as<float>(), ni * (int64_t)E, -2.f, h->ws_qtabh.as<uint16_t>(), h->stream);
+                if (ni >= 1024) {
+                    TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
+                    TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                    vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
+                                            h->have_rank ? h->list_rank.as<int>() : nullptr);
+                    a.qorder = h->ws_qorder.as<int>();
+                }
+                tq.stop();
+            }
+            a.term2h = h->term2h.as<uint16_t>();
+            a.qtabh = h->ws_qtabh.as<uint16_t>();
+            StageTimer tm(h, 2);
+            vlq::launch_scan16h(a, h->stream);
+            tm.stop();
+            continue;
+        }
         a.long_lists = h->ntotal >= (int64_t)h->nlist * 1024;   // mean list >= 4 chunks of 256 codes
         if (fast16) {
             // scan schedule (speed only): list-owned = one workgroup per (query, list partition), XCD x
@@ -497,7 +547,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     (void)hipStreamSynchronize(h->stream);
     drain_profile(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
+    DevBuf* bufs[] = {&h->term2h, &h->ws_qtabh, &h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->list_len, &h->list_rank, &h->list_part, &h->ws_own_hist, &h->ws_own_minr, &h->ws_own_order,
                       &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
@@ -608,6 +658,7 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     h->have_coarse = true;
     h->imi_nbits = 0;
     h->term2_valid = false;
+    h->term2h_valid = false;
     h->coarse_s_stride = 0;          // the sampled tiles belong to the old centroids
     return VLQ_OK;
 }
@@ -639,6 +690,7 @@ int vlq_ivfpq_set_imi_centroids(vlq_ivfpq_t h, int imi_nbits, const float* centr
     h->imi_nbits = imi_nbits;
     h->have_coarse = true;
     h->term2_valid = false;
+    h->term2h_valid = false;
     return VLQ_OK;
 }
 
@@ -658,6 +710,7 @@ int vlq_ivfpq_set_pq_centroids(vlq_ivfpq_t h, const float* centroids) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_pq = true;
     h->term2_valid = false;
+    h->term2h_valid = false;
     return VLQ_OK;
 }
 
@@ -671,6 +724,14 @@ int vlq_ivfpq_set_search_options(vlq_ivfpq_t h, int by_residual, int use_precomp
     h->by_residual = by_residual ? 1 : 0;
     h->use_precomputed_table = use_precomputed_table;
     h->max_codes = max_codes;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_float16_tables(vlq_ivfpq_t h, int enable) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (enable && !(h->M == 16 && h->ksub == 256))
+        return fail(VLQ_ERR_UNSUPPORTED, "float16 look-up tables are built for 16 x 8-bit codes only");
+    h->fp16_tables = enable != 0;
     return VLQ_OK;
 }
 

@@ -113,6 +113,9 @@ struct vlq_ivfpq_s {
     DevBuf ws_Dp, ws_Ip;          // partial top-k rows of the split scan (small batches)
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
         ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin;
+    // float16 look-up tables of the plain IVFPQ scan (vlq_ivfpq_set_float16_tables): half(term2), per-page half(term3)
+    bool fp16_tables = false, term2h_valid = false;
+    DevBuf term2h, ws_qtabh;
     DevBuf stats;   // [0] ncode (u64), [1] bad key flag (int)
     uint64_t stat_nq = 0;
 

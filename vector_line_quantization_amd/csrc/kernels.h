@@ -93,6 +93,9 @@ struct ScanArgs {
     unsigned long long* part_keys = nullptr; // [nq][8][k]
     const uint8_t* part_mask = nullptr;      // [nq] bit x: the query has a probe in partition x
     int qtab_scaled = 0;                     // qtab already holds (-2) * <q_m, cent_mj>
+    // float16 look-up tables (scan16h.hip): half(term2) [nlist][M*ksub] and half(-2 <q_m, cent_mj>) [nq][M*ksub]
+    const uint16_t* term2h = nullptr;
+    const uint16_t* qtabh = nullptr;
 };
 void launch_scan(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
@@ -107,6 +110,11 @@ inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
 void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
 void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
 void launch_owned_merge(const ScanArgs& a, hipStream_t s);
+// same shape with float16 look-up tables (useFloat16LookupTables; scan16h.hip), k <= 256
+bool scan16h_supports(const ScanArgs& a);
+void launch_scan16h(const ScanArgs& a, hipStream_t s);
+// *out = bit pattern of the largest |x[i]| (the half-range check of the float16 tables)
+void launch_max_abs(const float* x, int64_t n, unsigned int* out, hipStream_t s);
 // same shape, 256 < k <= 1024: one selection per workgroup instead of one per wave (scan16k.hip)
 void launch_scan16_bigk(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)

@@ -85,6 +85,10 @@ class GpuIVFPQ:
         check(lib().vlq_ivfpq_set_search_options(self._h, C.c_int(int(by_residual)),
                                                  C.c_int(use_precomputed_table), C.c_int64(max_codes)))
 
+    def set_float16_tables(self, enable=True):
+        """GpuIndexIVFPQConfig::useFloat16LookupTables for the plain IVFPQ search (include/vlq_ivfpq.h)"""
+        check(lib().vlq_ivfpq_set_float16_tables(self._h, C.c_int(int(enable))))
+
     def set_scan_schedule(self, mode):
         """0 automatic, 1 query-major, 2 list-owned (speed only; include/vlq_ivfpq.h)"""
         check(lib().vlq_ivfpq_set_scan_schedule(self._h, C.c_int(int(mode))))
