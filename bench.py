@@ -191,11 +191,50 @@ def second_dataset(torch, args, dev, steps=10):
     _n, ncode = g.stats(reset=True)
     scan_ms = prof["scan_ms"] / max(1, prof["scan_calls"])
     ncl = ncode / max(1, prof["scan_calls"])
-    r1, r10 = recall(torch, xq, xb, I.cpu().numpy(), a2.nb, dev)
-    return {"data": "synthetic, generator flags --sigma 0.005 --rank 12 --spread 0.4", "value": a2.nq / dt,
-            "unit": "queries/s", "ms_per_step": dt * 1e3, "scan_kernel_ms": scan_ms, "ncode_per_query": ncl / a2.nq,
-            "roofline_frac": (ncl * a2.M / (scan_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if scan_ms > 0 else 0.0,
-            "recall_at_1": r1, "recall_1_at_10": r10}
+    I32 = I.cpu().numpy()
+    r1, r10 = recall(torch, xq, xb, I32, a2.nb, dev)
+    out = {"data": "synthetic, generator flags --sigma 0.005 --rank 12 --spread 0.4", "value": a2.nq / dt,
+           "unit": "queries/s", "ms_per_step": dt * 1e3, "scan_kernel_ms": scan_ms, "ncode_per_query": ncl / a2.nq,
+           "roofline_frac": (ncl * a2.M / (scan_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS if scan_ms > 0 else 0.0,
+           "recall_at_1": r1, "recall_1_at_10": r10}
+    # The opt-in float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables) on the same data scaled by
+    # 1/256 -- a power of two, so every fp32 product, sum, list assignment and code is the scaled original and the
+    # vectors fit the half range (byte-valued coordinates do not: term 2 reaches 1e5).  8 KB rows instead of 16 KB.
+    try:
+        import vector_line_quantization_amd as vlq
+        sc = 1.0 / 256.0
+        g2 = vlq.GpuIVFPQ(a2.d, a2.nlist, a2.M, 8, device=dev.index or 0)
+        g2.set_stream(torch.cuda.current_stream().cuda_stream)
+        g2.set_coarse_centroids((coarse * sc).contiguous())
+        g2.set_pq_centroids((pq * sc).contiguous())
+        for i in range(0, a2.nb, 250000):
+            g2.add((xb[i:i + 250000] * sc).contiguous())
+        xq2 = (xq * sc).contiguous()
+        g2.set_float16_tables(True)
+        for _ in range(3):
+            g2.search(xq2, a2.nprobe, a2.k, D=D, I=I)
+        torch.cuda.synchronize()
+        g2.stats(reset=True)
+        g2.profile(True)
+        g2.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g2.search(xq2, a2.nprobe, a2.k, D=D, I=I)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / steps
+        prof2 = g2.profile_read(reset=True)
+        g2.profile(False)
+        I16 = I.cpu().numpy()
+        r1h, r10h = recall(torch, xq, xb, I16, a2.nb, dev)
+        out["float16_tables"] = {"value": a2.nq / dt2, "unit": "queries/s", "ms_per_step": dt2 * 1e3,
+                                 "scan_kernel_ms": prof2["scan_ms"] / max(1, prof2["scan_calls"]),
+                                 "recall_at_1": r1h, "recall_1_at_10": r10h,
+                                 "labels_equal_fp32_frac": float((I16 == I32).mean()),
+                                 "note": "opt-in (vlq_ivfpq_set_float16_tables), data scaled by 1/256 to fit the half range; "
+                                         "not the parity build"}
+    except Exception as e:     # noqa: BLE001
+        out["float16_tables"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
 
 
 def fvecs_read(path):
