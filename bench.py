@@ -683,15 +683,17 @@ def main():
     # FETCH_SIZE corrected x2 as the gfx950 guide prescribes) -- and ONLY while it still describes this run:
     # default workload, one GPU, and the scan-kernel sources unchanged since the passes were taken
     traffic, traffic_source = None, "null: no committed PMC passes match this workload and these kernel sources"
-    tpath = os.path.join(ROOT, "profiles", "r02_scan_traffic.json")
-    if os.path.exists(tpath) and default_workload and world == 1 and not fdir:
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_scan_traffic.json")))      # newest round last
+    if tfiles and default_workload and world == 1 and not fdir:
+        tname = "profiles/" + os.path.basename(tfiles[-1])
         try:
-            tj = json.load(open(tpath))
+            tj = json.load(open(tfiles[-1]))
             if tj.get("sources_sha256") == sources_sha():
                 traffic = tj["hbm_bytes_per_launch"]
-                traffic_source = "profiles/r02_scan_traffic.json (rocprofv3 --pmc passes of this command, same kernel sources)"
+                traffic_source = "%s (rocprofv3 --pmc passes of this command, same kernel sources)" % tname
             else:
-                traffic_source = "null: scan-kernel sources changed since profiles/r02_scan_traffic.json was taken"
+                traffic_source = "null: scan-kernel sources changed since %s was taken" % tname
         except Exception:
             traffic = None
 

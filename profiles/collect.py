@@ -26,11 +26,11 @@ with open(dst("long_lists.txt"), "w") as f:
     f.write("# tools/large_k.py (bench index, nprobe 32, 10 000 queries)\n")
     f.write(open(os.path.join(SRC, "large_k.txt")).read())
 with open(dst("imi_vlq.txt"), "w") as f:
-    for n in ("imi10.log", "imi14.log", "vlq4m.log", "vlq.log", "vlq_fp16.log"):
+    for n in ("imi10.log", "imi14.log", "vlq4m.log", "vlq.log", "vlq_fp16.log", "vlq_c5_1b.log", "vlq_c5_1b_fp16.log", "vlq_c5_1b_rows2.log"):
         if not os.path.exists(os.path.join(SRC, n)):
             continue
         lines = [l for l in open(os.path.join(SRC, n)).read().splitlines()
-                 if l.startswith(("added", "search", "look-up", "self-hit", "oracle sample", "VERIFIED")) ]
+                 if l.startswith(("added", "loaded", "search", "look-up", "self-hit", "oracle sample", "VERIFIED")) ]
         f.write("# %s\n%s\n" % (n, "\n".join(lines)))
 
 # HBM traffic of the scan kernel per launch: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts 64 B per

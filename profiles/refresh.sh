@@ -5,7 +5,7 @@
 # -> gpurun_out/r02/...   then copy the summaries into profiles/ (python profiles/collect.py r02).
 # Counter passes run without tracing domains.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 PART=${2:-ab}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -33,6 +33,9 @@ NB=16000000 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/
 NB=4000000 $T 300 python $REPO/tools/time_vlq.py > $OUT/vlq4m.log 2>&1
 FP16=1 NB=16000000 $T 300 python $REPO/tools/time_vlq.py > $OUT/vlq_fp16.log 2>&1
 $T 300 python $REPO/tools/sched_ab.py 20 2>/dev/null | grep -v "amdgpu\|^\[bench\]" > $OUT/sched_ab.txt
+SYNTH=1 NLIST=65536 NEDGE=64 NB=1000000000 CHECK=4 $T 300 python $REPO/tools/time_vlq.py 2000 5 > $OUT/vlq_c5_1b.log 2>&1
+SYNTH=1 NLIST=65536 NEDGE=64 NB=1000000000 CHECK=4 FP16=1 $T 300 python $REPO/tools/time_vlq.py 2000 5 > $OUT/vlq_c5_1b_fp16.log 2>&1
+SYNTH=1 NLIST=65536 NEDGE=64 NB=1000000000 CHECK=4 ROWS=2 $T 300 python $REPO/tools/time_vlq.py 2000 5 > $OUT/vlq_c5_1b_rows2.log 2>&1
 echo "imi/vlq done" >&2
 {
   for K in 10 100 256 1000; do K=$K $T 200 python $REPO/tools/long_lists.py 64000000 16384 10000 2>/dev/null | grep -v amdgpu; done
