@@ -80,3 +80,40 @@ def test_demo_sift1M_unchanged_on_the_device(tmp_path):
     assert len(rec_c) == 3 and len(rec_d) == 3
     if sel_c and sel_c == sel_d:
         assert rec_c == rec_d
+
+
+@pytest.mark.gpu
+def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
+    """tests/sift1b_imi_pq.cpp as shipped (inverted multi-index 2 x 14 bits = 2^28 lists, 8-byte codes, nprobe 2048,
+    k 128), compiled in place: CPU-only run, then the device run of the SAME binary on the cached populated index
+    the first run wrote.  Heavy (two 4.3 GB index files, ~40 GB of host memory, ~10 minutes): opt-in with
+    VLQ_RUN_SIFT1B_DRIVER=1; the run of record is profiles/r03_reference_drivers.txt.
+    The driver's training step (2 M vectors, k-means into 2 x 16 384 centroids on the host) is skipped through the
+    driver's own cache branch (:237-251): tools/make_driver_data.py writes the trained-index file it looks for."""
+    if os.environ.get("VLQ_RUN_SIFT1B_DRIVER") != "1":
+        pytest.skip("opt-in: VLQ_RUN_SIFT1B_DRIVER=1")
+    exe = os.path.join(RD, "sift1b_imi_pq")
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
+        pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
+    data, run = str(tmp_path / "data"), str(tmp_path / "run")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "sift1b", run, "500000", "1000"])
+    outs = {}
+    for mode in ("off", "on"):
+        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
+                           timeout=1000, cwd=run)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[mode] = (p.stdout, p.stderr)
+        print(mode, "\n".join(p.stdout.splitlines()[-6:]), p.stderr.splitlines()[-1])
+
+    def parse(out):
+        rec = [float(v) for v in re.findall(r"R@(?:1|10|100) = ([0-9.]+)", out)[-3:]]
+        ids = [tuple(int(v) for v in m.group(1).split()) for m in re.finditer(r"query\s+\d+:\s+((?:-?\d+\s+)+)", out)]
+        dis = [tuple(m.group(1).split()) for m in re.finditer(r"dis:\s+((?:\S+\s+)+?)\n", out)]
+        return rec, ids, dis
+    rc, ic, dc = parse(outs["off"][0])
+    rd, idd, dd = parse(outs["on"][0])
+    summ = re.search(r"\[vlq-interpose\] device searches=(\d+) queries=(\d+) ncode=(\d+)", outs["on"][1])
+    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 1000 and int(summ.group(3)) > 0
+    assert len(rc) == 3 and len(dc) == 10 and dc == dd                     # the printed distances, digit for digit
+    assert [sorted(a) for a in ic] == [sorted(b) for b in idd]             # the same neighbours (byte data: exact ties may swap)
+    assert max(abs(a - b) for a, b in zip(rc, rd)) <= 0.004

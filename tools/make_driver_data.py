@@ -3,7 +3,15 @@
 /home/data/sift1m/{learn,base,query}.fvecs + groundtruth.ivecs): generator G1 of SURVEY.md section 8(d) with
 real-valued noise (no exact distance ties, so CPU and device runs pick the same neighbours), exact ground
 truth by brute force.  The drivers' hard-coded /home/data prefix is redirected to <root> by the interposer
-(VLQ_DATA_ROOT).      python tools/make_driver_data.py <root> [nt nb nq]"""
+(VLQ_DATA_ROOT).      python tools/make_driver_data.py <root> [nt nb nq]
+                      python tools/make_driver_data.py <root> sift1b <cwd> [nb nq]
+The second form prepares tests/sift1b_imi_pq.cpp: byte-valued base.umem / query.umem / learn.umem ("num dim" text
+header, data from byte 20, :100-150), gnd/idx_1000M.ivecs, and -- in <cwd>, where the driver looks for its cache
+(:225-243) -- sift1b_14_8_trained_index.faissindex in the reference's file format (index_io.cpp:226-317): the
+driver's own training step is 2 M vectors of k-means into 2 x 16 384 centroids on the host, hours of CPU; the
+cached-index branch of the driver skips it.  The trained state written here (inverted multi-index 2 x 14 bits with
+sampled sub-centroids, 8 x 8-bit PQ sampled from residuals) is as good as any for what the test checks: the
+device run and the CPU-only run of the same binary must answer alike."""
 import os
 import sys
 
@@ -28,8 +36,103 @@ def ivecs_write(path, x):
     out.tofile(path)
 
 
+def write_imi_ivfpq_index(path, d, imi_nbits, imi_centroids, M, pq_centroids, lists=None, nprobe=1):
+    """IndexIVFPQ over a MultiIndexQuantizer 2 x imi_nbits in the reference's file format (index_io.cpp:226-317:
+    "IvPQ" header, nlist, nprobe, nested "Imiq" quantizer, one id vector per list, direct map, by_residual,
+    code_size, PQ, one code vector per list).  lists: None = all lists empty, else (codes[n][M] u8, ids[n] i64,
+    offsets[nlist+1])."""
+    import struct
+    nlist = 1 << (2 * imi_nbits)
+    hdr = lambda f, dd, ntotal: f.write(struct.pack("<iqqq?i", dd, ntotal, 1 << 20, 1 << 20, True, 1))
+
+    def vec(f, a):
+        a = np.ascontiguousarray(a)
+        f.write(struct.pack("<Q", a.size))
+        f.write(a.tobytes())
+
+    def pqrec(f, dd, MM, cent):
+        f.write(struct.pack("<QQQ", dd, MM, 8 if MM != 2 else imi_nbits))
+        vec(f, np.asarray(cent, np.float32))
+
+    def list_vectors(f, width, payload, offsets):
+        if offsets is None:        # every list: an 8-byte zero length
+            z = np.zeros(1 << 20, np.uint64)
+            for _ in range(nlist >> 20):
+                z.tofile(f)
+            np.zeros(nlist & ((1 << 20) - 1), np.uint64).tofile(f)
+            return
+        for i in range(nlist):
+            vec(f, payload[offsets[i] * width:offsets[i + 1] * width])
+
+    ntotal = 0 if lists is None else int(lists[2][-1])
+    with open(path, "wb") as f:
+        f.write(b"IvPQ")
+        hdr(f, d, ntotal)
+        f.write(struct.pack("<QQ", nlist, nprobe))
+        f.write(b"Imiq")
+        hdr(f, d, nlist)
+        pqrec(f, d, 2, imi_centroids)
+        list_vectors(f, 1, None if lists is None else np.asarray(lists[1], np.int64), None if lists is None else lists[2])
+        f.write(struct.pack("<?", False))
+        vec(f, np.zeros(0, np.int64))
+        f.write(struct.pack("<?Q", True, M))
+        pqrec(f, d, M, pq_centroids)
+        list_vectors(f, M, None if lists is None else np.asarray(lists[0], np.uint8).reshape(-1), None if lists is None else lists[2])
+
+
+def umem_write(path, x_u8):
+    n, d = x_u8.shape
+    with open(path, "wb") as f:
+        f.write(("%d %d\n" % (n, d)).encode().ljust(20, b" "))
+        np.ascontiguousarray(x_u8, np.uint8).tofile(f)
+
+
+def sift1b(root, cwd, nb=500000, nq=1000):
+    d, nc, sigma, rank, spread, kgt = 128, 2000, 0.005, 12, 0.4, 100
+    centres = np.random.default_rng(1).random((nc, d)).astype(np.float32)
+    sub = (np.random.default_rng(2).standard_normal((rank, d)) / np.sqrt(rank)).astype(np.float32)
+
+    def gen(seed, n):
+        r = np.random.default_rng(seed)
+        x = centres[r.integers(0, nc, n)] + sigma * r.standard_normal((n, d)) + spread * r.standard_normal((n, rank)) @ sub
+        return np.clip(np.rint(128.0 + 60.0 * (x - 0.5)), 0, 255).astype(np.uint8)
+
+    os.makedirs(os.path.join(root, "sift1b", "gnd"), exist_ok=True)
+    os.makedirs(cwd, exist_ok=True)
+    xb, xq = gen(22, nb), gen(33, nq)
+    umem_write(os.path.join(root, "sift1b", "base.umem"), xb)
+    umem_write(os.path.join(root, "sift1b", "query.umem"), xq)
+    umem_write(os.path.join(root, "sift1b", "learn.umem"), gen(11, 1000))     # read, never used: the cached index is
+    xbf, xqf = xb.astype(np.float64), xq.astype(np.float64)
+    bn = (xbf ** 2).sum(1)
+    gt = np.empty((nq, kgt), np.int32)
+    for i in range(0, nq, 256):
+        dist = bn[None, :] - 2.0 * xqf[i:i + 256] @ xbf.T
+        idx = np.argpartition(dist, kgt, axis=1)[:, :kgt]
+        o = np.argsort(np.take_along_axis(dist, idx, 1), axis=1, kind="stable")
+        gt[i:i + 256] = np.take_along_axis(idx, o, 1)
+    ivecs_write(os.path.join(root, "sift1b", "gnd", "idx_1000M.ivecs"), gt)
+    # the trained state the driver's cache branch loads: 2 x 16 384 sub-centroids sampled from the data's halves
+    # (de-duplicated by a tiny jitter), 8 x 256 PQ centroids sampled from residuals to them
+    r = np.random.default_rng(5)
+    nbits, kc, M = 14, 1 << 14, 8
+    tr = gen(44, 60000).astype(np.float32)
+    imi = np.stack([tr[r.permutation(tr.shape[0])[:kc], h * 64:(h + 1) * 64] for h in range(2)])
+    imi = (imi + 0.25 * r.standard_normal(imi.shape)).astype(np.float32)
+    res = np.empty_like(tr[:20000])
+    for h in range(2):
+        sl = slice(h * 64, (h + 1) * 64)
+        a = (((imi[h] ** 2).sum(1))[None, :] - 2.0 * tr[:20000, sl] @ imi[h].T).argmin(1)
+        res[:, sl] = tr[:20000, sl] - imi[h][a]
+    pq = np.stack([res[r.permutation(20000)[:256], m * 16:(m + 1) * 16] for m in range(M)]).astype(np.float32)
+    write_imi_ivfpq_index(os.path.join(cwd, "sift1b_14_8_trained_index.faissindex"), d, nbits, imi, M, pq)
+    print("wrote %s/sift1b (base %d, query %d, ground truth %d) and %s/sift1b_14_8_trained_index.faissindex" % (root, nb, nq, kgt, cwd))
+
+
 def main():
     root = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == "sift1b":
+        return sift1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:6]))
     nt, nb, nq = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (40000, 200000, 1000)
     # low intrinsic dimension (what makes real descriptors rankable by short codes, bench.py's second data set):
     # most of a point's offset from its centre lies in one fixed 12-dimensional subspace
