@@ -142,7 +142,8 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
     int fs = 0, fcap = 0;
     const bool filtered = !direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_filter &&
                           vlq::coarse_filter_ok(h->nlist, h->d, nprobe, n, &fs, &fcap);
-    if (!argmin && !filtered) TRY(h->ws_dist.reserve((size_t)n * h->nlist * sizeof(float)));
+    const int64_t n_pad = (n + 127) / 128 * 128;       // whole 128-row blocks: the pipelined distance kernel stores without a row guard
+    if (!argmin && !filtered) TRY(h->ws_dist.reserve((size_t)n_pad * h->nlist * sizeof(float)));
     if (filtered) {
         // filtered coarse stage: no [n][nlist] matrix.  (1) exact distances to a sample of the column tiles
         // and their nprobe smallest -> the nprobe-th is an upper bound of the row's nprobe-th smallest overall;
@@ -189,7 +190,7 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
         }
         vlq::launch_coarse_distances(x_dev, h->coarse.as<float>(), fused_norms ? nullptr : h->ws_qn.as<float>(),
                                      h->cnorm.as<float>(), argmin ? nullptr : h->ws_dist.as<float>(), n,
-                                     h->nlist, h->d, h->stream, tmin);
+                                     h->nlist, h->d, h->stream, tmin, argmin ? 0 : n_pad);
     }
     if (argmin)
         vlq::launch_coarse_argmin(tmin, n, h->nlist, cdis_dev, keys_dev, h->stream);
@@ -207,7 +208,8 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     const int kc = 1 << h->imi_nbits, dc = h->d / 2;
     const int T = std::min(k, kc);
     // workspace: 2 tables [n][kc] | sorted values 2x[n][T] | sorted ids 2x[n][T] | heap
-    const size_t b_tab = (size_t)n * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
+    const int64_t n_pad = (n + 127) / 128 * 128;
+    const size_t b_tab = (size_t)n_pad * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
     const size_t b_hv = (size_t)n * 2 * k * 4, b_hi = (size_t)n * 2 * k * 8, b_sub = (size_t)n * dc * 4;
     TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + b_sub + 256));
     char* p = h->ws_imi.as<char>();
@@ -244,7 +246,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
                 tmin = h->ws_tmin.as<float>();
             }
             vlq::launch_coarse_distances(sub, cent, h->ws_qn.as<float>(), h->imi_norm.as<float>() + (size_t)m * kc,
-                                         argmin ? nullptr : tab[m], n, kc, dc, h->stream, tmin);
+                                         argmin ? nullptr : tab[m], n, kc, dc, h->stream, tmin, argmin ? 0 : n_pad);
         }
         if (argmin) vlq::launch_coarse_argmin(tmin, n, kc, sv[m], si[m], h->stream);
         else vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);

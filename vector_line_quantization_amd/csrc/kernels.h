@@ -18,8 +18,11 @@ void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t 
 // k-ordered f32 MFMA chain.  out is [nq][nlist].  qn == nullptr (d <= 128 only, coarse_norms_fused_ok): the
 // kernel computes |q_i|^2 itself, in fvec_norm_L2sqr's order, from the query tile it stages anyway.
 // tmin != nullptr (only if coarse_tile_minima_ok): also tmin[i][t] = min of out[i][64t .. 64t+63]
+// out_rows: rows the caller allocated for `out`; with room for whole 128-row blocks (>= round_up(nq, 128)) the
+// software-pipelined loop runs, which stores its blocks without a row guard (rows past nq: written, never read)
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
-                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin = nullptr);
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin = nullptr,
+                             int64_t out_rows = 0);
 inline bool coarse_norms_fused_ok(int d) { return d <= 128; }
 // wide rows and few probes: the distance kernel can hand the select a [nq][nlist/64] matrix of tile minima
 bool coarse_tile_minima_ok(int nlist, int d, int nprobe);

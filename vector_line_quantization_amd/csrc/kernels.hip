@@ -297,6 +297,90 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     stash(0);
     if (tile0 + 1 < tend) fetch(tile0 + 1);
     __syncthreads();
+    if (TMIN == 7) {
+        // Software pipeline over HALF tiles (round 3): the matrix stores of a tile were what the plain loop paid 33
+        // of its 125 us for -- the epilogue of a tile sat between its MFMAs and the next tile's.  Here the two
+        // 32-column halves of a tile keep their two accumulators but are multiplied one after the other, and the
+        // 64 MFMAs of one half and the epilogue of the half before it -- distances, 4x4 transposes, 16-byte stores --
+        // are ONE basic block (every row of the workgroup and every column of the tile exists: the launcher hands
+        // partial row blocks to the plain kernel), scheduled so that the VALU work and the stores issue in the MFMA
+        // shadow.  No register more than the plain loop: two workgroups per CU as before.  Same products, same k
+        // order per element, same epilogue arithmetic: bit-identical output.
+        auto mfma_half = [&](int buf, int tj, f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
+            const float* bsrc = sm + buf * BUF + h * 64 * S + (tj * 32 + r) * S;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bsrc + 4 * u);
+                const float4 av = areg[u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc, 0, 0, 0);
+            }
+        };
+        auto epilogue_half = [&](int tile, int tj, const f32x16& acc) __attribute__((always_inline)) {
+            const float cnv = cn[tile * 64 + tj * 32 + r];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)   // (x_norm + y_norm) - 2*ip, utils.cpp:884
+                    v[i] = __fsub_rn(__fadd_rn(qnr[4 * g + i], cnv), __fmul_rn(2.f, acc[4 * g + i]));
+                {
+                    const bool odd = lane & 1;
+                    float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
+                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, false));
+                    if (odd) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+                }
+                {
+                    const bool up = lane & 2;
+                    float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3];
+                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x4E, 0xf, 0xf, false));
+                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xf, 0xf, false));
+                    if (up) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
+                }
+                const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + (r & 3);
+                *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        };
+        // issue order of a block: per MFMA two VALU operations of the epilogue; an LDS read of the next B operand
+        // every 4th MFMA, a matrix store every 16th (0x8 MFMA, 0x2 VALU, 0x100 DS read, 0x40 VMEM write)
+        auto schedule = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4 * NU; i++) {
+                if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (i % 16 == 15) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+        };
+        f32x16 acc0, acc1;
+        mfma_half(0, 0, acc0);                       // first tile, first half: nothing to overlap with yet
+        for (int tile = tile0; tile < tend; tile++) {
+            const int buf = (tile - tile0) & 1;
+            mfma_half(buf, 1, acc1);
+            epilogue_half(tile, 0, acc0);
+            schedule();
+            // every wave has read its B operands of this tile: the next tile's registers go to the other buffer
+            // (free since the barrier of the previous iteration), the tile after it is requested
+            if (tile + 1 < tend) {
+                stash(buf ^ 1);
+                if (tile + 2 < tend) fetch(tile + 2);
+            }
+            __syncthreads();
+            if (tile + 1 < tend) {
+                mfma_half(buf ^ 1, 0, acc0);
+                epilogue_half(tile, 1, acc1);
+                schedule();
+            } else {
+                epilogue_half(tile, 1, acc1);
+            }
+        }
+        return;
+    }
     for (int tile = tile0; tile < tend; tile++) {
         const int buf = (tile - tile0) & 1;
         f32x16 acc[2];
@@ -481,9 +565,14 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
 
 template <int NU>
 static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
-                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s) {
+                               float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s, int64_t out_rows) {
     if (tmin && !out) launch_coarse_areg_t<NU, true, 3>(q, c, qn, cn, out, nq, nlist, d, tmin, s);   // coarse_argmin_ok
     else if (tmin) launch_coarse_areg_t<NU, true, 1>(q, c, qn, cn, out, nq, nlist, d, tmin, s);       // coarse_tile_minima_ok
+    else if (d % 4 == 0 && d >= 4 && nlist % 64 == 0 && out_rows >= (nq + 127) / 128 * 128 && !getenv("VLQ_COARSE_PLAIN")) {
+        // plain matrix, whole tiles, and the matrix has room for whole 128-row blocks (rows past nq are written and
+        // never read): the pipelined loop, whose epilogue has no row guard
+        launch_coarse_areg_t<NU, true, 7>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
+    }
     else if (d % 4 == 0 && d >= 4) launch_coarse_areg_t<NU, true, 0>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
     else launch_coarse_areg_t<NU, false, 0>(q, c, qn, cn, out, nq, nlist, d, nullptr, s);
 }
@@ -648,13 +737,13 @@ void launch_coarse_argmin(const void* tkeys, int64_t nq, int nlist, float* cdis,
 }
 
 void launch_coarse_distances(const float* q, const float* c, const float* qn, const float* cn,
-                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin) {
+                             float* out, int64_t nq, int nlist, int d, hipStream_t s, float* tmin, int64_t out_rows) {
     if (nq <= 0 || nlist <= 0) return;
     if (d <= 128) {
-        if (d <= 32) launch_coarse_areg<4>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
-        else if (d <= 64) launch_coarse_areg<8>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
-        else if (d <= 96) launch_coarse_areg<12>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
-        else launch_coarse_areg<16>(q, c, qn, cn, out, nq, nlist, d, tmin, s);
+        if (d <= 32) launch_coarse_areg<4>(q, c, qn, cn, out, nq, nlist, d, tmin, s, out_rows);
+        else if (d <= 64) launch_coarse_areg<8>(q, c, qn, cn, out, nq, nlist, d, tmin, s, out_rows);
+        else if (d <= 96) launch_coarse_areg<12>(q, c, qn, cn, out, nq, nlist, d, tmin, s, out_rows);
+        else launch_coarse_areg<16>(q, c, qn, cn, out, nq, nlist, d, tmin, s, out_rows);
         return;
     }
     constexpr int KC = 64;
