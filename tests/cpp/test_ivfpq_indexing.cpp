@@ -14,6 +14,7 @@
 #include "faiss_amd/gpu/GpuClonerOptions.h"
 #include "faiss_amd/gpu/GpuIndexIVFPQ.h"
 #include "faiss_amd/gpu/IndexProxy.h"
+#include "faiss_amd/gpu/RcclShardedIndex.h"
 #include "faiss_amd/gpu/StandardGpuResources.h"
 #include "faiss_amd/index_io.h"
 
@@ -272,6 +273,32 @@ int main() {
     gp.search(nq, pq, k, pD, pI);
     EXPECT(std::equal(nns.begin(), nns.end(), pI) && std::equal(dis.begin(), dis.end(), pD));
     printf("part 2g: %zu MB of pinned memory from GpuResources; search from / into it equals the pageable call\n", pin.second >> 20);
+  }
+
+  // part 2h: the RCCL host in C++ (north star: "host code stays C++ ... RCCL all-gather of per-shard top-k"):
+  // replicas, ceil(n / G) slices, one grouped all-gather per output array.  One GPU on the box = one rank; the slice
+  // arithmetic for G > 1 is checked on its own.
+  {
+    long lo, hi, per;
+    faiss::gpu::RcclShardedIndex::sliceOf(10000, 8, 7, &lo, &hi, &per);
+    EXPECT(per == 1250 && lo == 8750 && hi == 10000);
+    faiss::gpu::RcclShardedIndex::sliceOf(10, 8, 5, &lo, &hi, &per);       // IndexProxy.cpp:139-149: short and empty slices
+    EXPECT(per == 2 && lo == 10 && hi == 10);
+    faiss::gpu::RcclShardedIndex::sliceOf(10, 8, 4, &lo, &hi, &per);
+    EXPECT(lo == 8 && hi == 10);
+    faiss::gpu::StandardGpuResources rres;
+    faiss::gpu::GpuIndexIVFPQ rep(&rres, &index);
+    rep.setNumProbes(5);
+    faiss::gpu::RcclShardedIndex sharded({&rep});
+    std::vector<faiss::Index::idx_t> sn((size_t)k * nq);
+    std::vector<float> sd((size_t)k * nq);
+    sharded.search(nq, queries.data(), k, sd.data(), sn.data());
+    EXPECT(sn == nns && sd == dis);
+    // a second, smaller batch through the same buffers (>= 20 queries: below that the reference's coarse path --
+    // and ours -- is the SSE one, which rounds differently from the GEMM path, utils.cpp:935-946)
+    sharded.search(40, queries.data(), k, sd.data(), sn.data());
+    EXPECT(std::equal(sn.begin(), sn.begin() + 40 * k, nns.begin()) && std::equal(sd.begin(), sd.begin() + 40 * k, dis.begin()));
+    printf("part 2h: RcclShardedIndex (%d rank): rows gathered over RCCL equal the single index\n", sharded.numReplicas());
   }
 
   // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of
