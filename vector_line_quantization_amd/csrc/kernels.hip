@@ -231,6 +231,29 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         return x;
     };
 
+    float4 areg[NU];
+    float* qns = sm + 2 * BUF + (TMIN == 1 ? 4 * 32 * 17 : 0);       // [128]
+    if (VEC) {
+        // ---- A fragments straight from global memory (round 3): lane (h, r) owns row wave*32 + r and, of every 8
+        // consecutive k, the four of parity h -- two 16-byte loads per 8 k, no LDS staging, no workgroup barrier.
+        // The row norm (qn == nullptr) falls out of the same loads in fvec_norm_L2sqr's order (utils.cpp:538-556:
+        // lane sums over k = 4j + l, then (s0 + s1) + (s2 + s3); the zero-padded k add +0 to non-negative sums).
+        const int64_t grow = i0 + wave * 32 + r;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const float4 x0 = load4(Q, grow, nq, 8 * u), x1 = load4(Q, grow, nq, 8 * u + 4);
+            areg[u] = h ? make_float4(x0.y, x0.w, x1.y, x1.w) : make_float4(x0.x, x0.z, x1.x, x1.z);
+            s0 = __fadd_rn(s0, __fmul_rn(x0.x, x0.x)); s1 = __fadd_rn(s1, __fmul_rn(x0.y, x0.y));
+            s2 = __fadd_rn(s2, __fmul_rn(x0.z, x0.z)); s3 = __fadd_rn(s3, __fmul_rn(x0.w, x0.w));
+            s0 = __fadd_rn(s0, __fmul_rn(x1.x, x1.x)); s1 = __fadd_rn(s1, __fmul_rn(x1.y, x1.y));
+            s2 = __fadd_rn(s2, __fmul_rn(x1.z, x1.z)); s3 = __fadd_rn(s3, __fmul_rn(x1.w, x1.w));
+        }
+        if (!qn) {
+            if (h == 0) qns[wave * 32 + r] = __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
+            __builtin_amdgcn_wave_barrier();      // the 32 rows a wave reads below are the 32 it wrote
+        }
+    } else {
     // ---- stage the 128-row query tile through LDS (uses both buffers), pull A fragments
     for (int f = t; f < 128 * (2 * NU); f += 256) {
         const int row = f / (2 * NU), v = f % (2 * NU);
@@ -241,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         *reinterpret_cast<float2*>(base + 64 * S) = make_float2(x.y, x.w);
     }
     __syncthreads();
-    float4 areg[NU];
     {
         const int row = wave * 32 + r;
         const float* src = sm + (row >> 6) * BUF + h * 64 * S + (row & 63) * S;
@@ -251,13 +273,13 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     // qn == nullptr: the query norms are computed here, from the staged tile, in the reference's own order
     // (fvec_norms_L2sqr -> fvec_norm_L2sqr, utils.cpp:538-556, :675-682: norm_sse_order) -- one launch less
     // per coarse call; element k of a staged row sits in parity plane k & 1 at column k >> 1
-    float* qns = sm + 2 * BUF + (TMIN == 1 ? 4 * 32 * 17 : 0);       // [128]
     if (!qn) {
         if (t < 128) {
             const float* rowp = sm + (t >> 6) * BUF + (t & 63) * S;
             qns[t] = norm_sse_order([&](int c) { return rowp[(c & 1) * 64 * S + (c >> 1)]; }, d);
         }
         __syncthreads();
+    }
     }
     float qnr[16];
     float bnd[TMIN == 5 ? 16 : 1];
@@ -549,15 +571,20 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
     const int64_t rb = (nq + 127) / 128;
     const int ntiles = (nlist + 63) / 64;
     // tiles per workgroup: the MFMA pipe of a CU is shared by its (up to 2) resident
-    // workgroups, so the time is ~ (tiles + prologue) of the busiest CU over all rounds
+    // workgroups, so the time is ~ (tiles + prologue) of the busiest CU over all rounds.  The prologue (query
+    // tile through LDS, norms, first centroid tile) costs about 1.2 tile times (round 3, measured at C1 under
+    // rocprof: 4 tiles per workgroup 128 us, 11 tiles 121 us, 22 tiles -- one workgroup per CU, nothing to overlap
+    // with -- 132 us); a CU with a single resident workgroup loses the overlap of the second one.
     int best_t = 1;
     double best_cost = 1e30;
     for (int tpb = 1; tpb <= 32; tpb++) {
         const int64_t blocks = rb * ((ntiles + tpb - 1) / tpb);
         const int64_t per_cu = (blocks + 255) / 256;            // workgroups the busiest CU runs
-        const double cost = (double)per_cu * (tpb + 0.5);
+        double cost = (double)per_cu * (tpb + 1.2);
+        if (per_cu < 2 && blocks > 256 / 2) cost *= 1.1;        // lone workgroups: nothing hides their barriers
         if (cost < best_cost) { best_cost = cost; best_t = tpb; }
     }
+    if (const char* e = getenv("VLQ_COARSE_TPB")) { const int v = atoi(e); if (v >= 1 && v <= 64) best_t = v; }   // A/B only
     dim3 grid((unsigned)rb, (unsigned)((ntiles + best_t - 1) / best_t));
     hipLaunchKernelGGL((coarse_dist_areg_kernel<NU, VEC, TMIN>), grid, dim3(256), smem, s, q, c, qn, cn, out,
                        nq, nlist, d, best_t, tmin, flt);
