@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     };
 
     float4 areg[NU];
-    float* qns = sm + 2 * BUF + (TMIN == 1 ? 4 * 32 * 17 : 0);       // [128]
+    float* qns = sm + 2 * BUF + ((TMIN == 1 || TMIN == 8) ? 4 * 32 * 17 : 0);       // [128]
     if (VEC) {
         // ---- A fragments straight from global memory (round 3): lane (h, r) owns row wave*32 + r and, of every 8
         // consecutive k, the four of parity h -- two 16-byte loads per 8 k, no LDS staging, no workgroup barrier.
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
     stash(0);
     if (tile0 + 1 < tend) fetch(tile0 + 1);
     __syncthreads();
-    if (TMIN == 7) {
+    if (TMIN == 7 || TMIN == 8) {     // 8 = 7 + the per-tile row minima of TMIN == 1
         // Software pipeline over HALF tiles (round 3): the matrix stores of a tile were what the plain loop paid 33
         // of its 125 us for -- the epilogue of a tile sat between its MFMAs and the next tile's.  Here the two
         // 32-column halves of a tile keep their two accumulators but are multiplied one after the other, and the
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         // partial row blocks to the plain kernel), scheduled so that the VALU work and the stores issue in the MFMA
         // shadow.  No register more than the plain loop: two workgroups per CU as before.  Same products, same k
         // order per element, same epilogue arithmetic: bit-identical output.
+        float pmrow[4] = {0.f, 0.f, 0.f, 0.f};     // TMIN == 8: running minimum of the tile's columns per row group
         auto mfma_half = [&](int buf, int tj, f32x16& acc) __attribute__((always_inline)) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
@@ -366,6 +367,34 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                 }
                 const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + (r & 3);
                 *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) = make_float4(v[0], v[1], v[2], v[3]);
+                if (TMIN == 8) {
+                    const float m4 = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                    pmrow[g] = tj == 0 ? m4 : fminf(pmrow[g], m4);
+                }
+            }
+        };
+        // TMIN == 8, after both halves of a tile: the rows' tile minima (over lane bits 2..4), staged per wave and
+        // written 16 tiles at a time -- the code of the plain loop's TMIN == 1 branch
+        auto tile_minima = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float m = pmrow[g];
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 4)));
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 8)));
+                m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 16)));
+                if (r < 4) tms[(8 * g + 4 * h + r) * 17 + ((tile - tile0) & 15)] = m;
+            }
+            const int done = tile - tile0 + 1;
+            if ((done & 15) == 0 || tile + 1 == tend) {
+                __builtin_amdgcn_wave_barrier();
+                const int ncol = ((done - 1) & 15) + 1, t0 = tile + 1 - ncol, c = lane & 15;
+#pragma unroll
+                for (int rr = 0; rr < 32; rr += 4) {
+                    const int lr = rr + (lane >> 4);
+                    const int64_t row = i0 + wave * 32 + lr;
+                    if (c < ncol && row < nq) tmin[row * (nlist >> 6) + t0 + c] = tms[lr * 17 + c];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         };
         // issue order of a block: per MFMA two VALU operations of the epilogue; an LDS read of the next B operand
@@ -400,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
             } else {
                 epilogue_half(tile, 1, acc1);
             }
+            if (TMIN == 8) tile_minima(tile);
         }
         return;
     }
@@ -565,7 +595,7 @@ static void launch_coarse_areg_t(const float* q, const float* c, const float* qn
                                float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s,
                                CoarseFilter flt = CoarseFilter{nullptr, 0, nullptr, nullptr, 0}) {
     constexpr int S = 4 * NU + 4;
-    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + (TMIN == 1 ? (size_t)4 * 32 * 17 * sizeof(float) : 0) +
+    const size_t smem = (size_t)2 * 2 * 64 * S * sizeof(float) + ((TMIN == 1 || TMIN == 8) ? (size_t)4 * 32 * 17 * sizeof(float) : 0) +
                         128 * sizeof(float);      // + the fused query norms
     ensure_dynamic_lds(reinterpret_cast<const void*>(coarse_dist_areg_kernel<NU, VEC, TMIN>), smem);
     const int64_t rb = (nq + 127) / 128;
@@ -594,6 +624,8 @@ template <int NU>
 static void launch_coarse_areg(const float* q, const float* c, const float* qn, const float* cn,
                                float* out, int64_t nq, int nlist, int d, float* tmin, hipStream_t s, int64_t out_rows) {
     if (tmin && !out) launch_coarse_areg_t<NU, true, 3>(q, c, qn, cn, out, nq, nlist, d, tmin, s);   // coarse_argmin_ok
+    else if (tmin && out_rows >= (nq + 127) / 128 * 128 && !getenv("VLQ_COARSE_PLAIN"))
+        launch_coarse_areg_t<NU, true, 8>(q, c, qn, cn, out, nq, nlist, d, tmin, s);                   // coarse_tile_minima_ok, pipelined
     else if (tmin) launch_coarse_areg_t<NU, true, 1>(q, c, qn, cn, out, nq, nlist, d, tmin, s);       // coarse_tile_minima_ok
     else if (d % 4 == 0 && d >= 4 && nlist % 64 == 0 && out_rows >= (nq + 127) / 128 * 128 && !getenv("VLQ_COARSE_PLAIN")) {
         // plain matrix, whole tiles, and the matrix has room for whole 128-row blocks (rows past nq are written and
