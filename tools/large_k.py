@@ -7,7 +7,7 @@ dev = torch.device("cuda", 0)
 g, centres, coarse, pq, xb = bench.build_index(a, dev)
 gen = torch.Generator(device=dev); gen.manual_seed(33)
 xq = bench.gmm(torch, gen, centres, 10000, a.sigma, dev)
-for k in (256, 257, 512, 1000):
+for k in [int(v) for v in os.environ.get("KS", "256,257,512,1000").split(",")]:
     D = torch.empty((10000, k), dtype=torch.float32, device=dev); I = torch.empty((10000, k), dtype=torch.int64, device=dev)
     g.search(xq, 32, k, D=D, I=I); torch.cuda.synchronize()
     g.profile(True); g.profile_read(reset=True)

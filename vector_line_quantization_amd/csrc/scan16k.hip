@@ -30,39 +30,78 @@ namespace {
 
 constexpr int kPendCap = 1024;      // shared pending queue (keys); a trip appends at most 256
 
-// ascending bitonic sort of a[0..N) in LDS by the 256 threads of the workgroup (N a power of two >= 512)
-template <int N>
-__device__ __forceinline__ void wg_bitonic_sort(u64* a, int t) {
-    for (int size = 2; size <= N; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-            for (int p0 = 0; p0 < N / 2; p0 += 256) {
-                const int p = p0 + t;
-                const int i = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
-                const int j = i | stride;
-                const u64 x = a[i], y = a[j];
-                const bool up = (i & size) == 0 || size == N;
-                if ((x > y) == up) { a[i] = y; a[j] = x; }
-            }
-            __syncthreads();
-        }
-    }
+// wave-wide minimum / inclusive prefix sum without LDS traffic: DPP inside the rows of 16 lanes, readlane across rows
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));     // quad_perm:[1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));     // quad_perm:[2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));    // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ int wave_inclusive_sum(int x, int lane) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);      // row_shr:1 (lanes without a source keep 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);      // row_shr:8
+    const int s0 = __builtin_amdgcn_readlane(x, 15), s1 = __builtin_amdgcn_readlane(x, 31), s2 = __builtin_amdgcn_readlane(x, 47);
+    const int row = lane >> 4;
+    return x + (row >= 1 ? s0 : 0) + (row >= 2 ? s1 : 0) + (row >= 3 ? s2 : 0);
 }
 
-// a[0..N) bitonic -> ascending
+// Ascending bitonic sort of a[0..N) in LDS by the 4 waves of the workgroup (N = 512 or 1024).  A wave keeps its N / 4
+// consecutive keys in registers (element r * 64 + lane of its chunk): of the network's stages only the three whose
+// partner lies in another wave's chunk go through LDS and a workgroup barrier; strides of 64 and more inside a chunk are
+// register pairs, smaller ones lane exchanges.  (One barrier per stage -- 45 / 55 of them -- was 10 % of the k = 1000
+// kernel.)
 template <int N>
-__device__ __forceinline__ void wg_bitonic_merge(u64* a, int t) {
-    for (int stride = N >> 1; stride > 0; stride >>= 1) {
+__device__ __forceinline__ void wg_bitonic_sort(u64* a, int t) {
+    constexpr int R = N / 256, CH = 64 * R;          // keys per lane, keys per wave
+    const int lane = t & 63, gbase = (t >> 6) * CH;
+    u64 v[R];
 #pragma unroll
-        for (int p0 = 0; p0 < N / 2; p0 += 256) {
-            const int p = p0 + t;
-            const int i = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
-            const int j = i | stride;
-            const u64 x = a[i], y = a[j];
-            if (x > y) { a[i] = y; a[j] = x; }
+    for (int r = 0; r < R; r++) v[r] = a[gbase + r * 64 + lane];
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= CH) {
+#pragma unroll
+                for (int r = 0; r < R; r++) a[gbase + r * 64 + lane] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int gi = gbase + r * 64 + lane;
+                    const bool up = (gi & size) == 0 || size == N, lower = (gi & stride) == 0;
+                    v[r] = pick64(v[r], a[gi ^ stride], lower == up);
+                }
+                __syncthreads();
+            } else if (stride >= 64) {
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((r & rs) == 0) {
+                        const bool up = ((gbase + r * 64) & size) == 0 || size == N;
+                        const u64 x = v[r], y = v[r | rs];
+                        const bool keep = (x < y) == up;
+                        v[r] = keep ? x : y;
+                        v[r | rs] = keep ? y : x;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int gi = gbase + r * 64 + lane;
+                    const bool up = (gi & size) == 0 || size == N, lower = (lane & stride) == 0;
+                    v[r] = pick64(v[r], shfl_xor_u64(v[r], stride), lower == up);
+                }
+            }
         }
-        __syncthreads();
     }
+#pragma unroll
+    for (int r = 0; r < R; r++) a[gbase + r * 64 + lane] = v[r];
+    __syncthreads();
 }
 
 }  // namespace
@@ -72,14 +111,16 @@ template <int KC, bool IMI>
 __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_region) {
     constexpr int E = 4096, NT = 256, NI = 4, NW = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-    float* lut = reinterpret_cast<float*>(smraw);                         // [2][E] at LDS offsets 0 / 16384
+    float* lut = reinterpret_cast<float*>(smraw);                         // [E] at LDS offset 0: ONE table (36.5 KB per workgroup: 4 per CU)
     u64* best = reinterpret_cast<u64*>(smraw + lut_region);               // [KC] the best keys so far (unsorted until the end)
     u64* pend = best + KC;                                                // [kPendCap] queue, contiguous behind them
+    int32_t* hist = reinterpret_cast<int32_t*>(pend + kPendCap);          // [3][256] bucket counts of a flush
+    u64* small = reinterpret_cast<u64*>(hist + 3 * 256);                  // [64] the last keys of a selection
     ProbeMeta pm;
-    pm.carve(reinterpret_cast<unsigned char*>(pend + kPendCap), a.nprobe);
-    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(pend + kPendCap) +
-                                               ProbeMeta::bytes(a.nprobe));    // cut, nlive, npend, thr bits, [2][4] trip counts, select state
-    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 20);                     // [nprobe] visited probes
+    pm.carve(reinterpret_cast<unsigned char*>(small + 64), a.nprobe);
+    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(small + 64) +
+                                               ProbeMeta::bytes(a.nprobe));    // cut, nlive, npend, -, [2][4] trip counts, flush state
+    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 26);                     // [nprobe] visited probes (misc[22..25]: min / max key of a flush)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (__builtin_amdgcn_groupstaticsize() != 0) { *a.bad_key = 2; return; }
@@ -116,105 +157,132 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
     float thr = 3.402823466e+38f;          // distance of the k-th best key so far, or FLT_MAX
 
     // keep the k smallest keys of best[0..KC) + pend[0..n); every thread of the workgroup calls it.
-    // misc[12] = digit chosen, misc[13] = rank still wanted inside it, misc[14] = candidates left,
-    // misc[15..16] = the k-th key, misc[17] / misc[18] = hole / mover counts
-    // Scratch of a flush (digit counts, hole and mover lists: 5 KB) lives in the LUT buffer that is NOT in
-    // use: while probe i is scanned from buffer `buf`, the other buffer's table (probe i-1) is consumed and
-    // the next one is built only after this probe's last trip.
-    int buf = 0;
+    // The kernel is bound by LDS gathers: while one workgroup flushes, the CU's other workgroups keep the LDS pipe full,
+    // and every LDS round trip or barrier of the flush waits behind their requests (measured: ~1000 cycles for a
+    // 256-counter prefix scan by one wave).  So the flush is organised as FEW dependent LDS steps (round 3):
+    //   * a thread holds its KPT keys of the contiguous array best | pend in registers throughout;
+    //   * the k-th smallest key is found by bucket counts over the band the keys actually occupy: lo / hi = smallest
+    //     / largest ordered distance (register minima, DPP row reductions), bucket = (key - lo) >> s with s the
+    //     smallest shift that maps the band onto 256 buckets, the bucket holding rank k is the next band.  (Byte-wise
+    //     radix passes from the top spent two passes on digits nearly every key shares -- 64 lanes adding to two or
+    //     three counters.)  One barrier per pass: three counter arrays rotate, EVERY wave reads the counters and finds
+    //     the bucket itself (DPP prefix sums, readlane), nothing is broadcast through LDS;
+    //   * a band of at most 64 keys (runs of equal distances -- identical codes -- would otherwise cost a pass per 8
+    //     bits down to the position bits) is gathered and ranked by every wave with readlane loops;
+    //   * keys are unique (the scan position is part of them), so a band of one bucket of width 1 IS the key;
+    //   * keepers of the queue are written, as keys, over the front of the queue (every thread has its keys in
+    //     registers by then); the j-th hole the losers leave in the best area takes the j-th of them.
+    // misc[17] / misc[18] = hole / mover counts, misc[19] = keys gathered, misc[22] / misc[23] = min / max distance.
+    int nreal = 0;                             // real keys in the best area (every thread knows it)
+    constexpr int KPT = (KC + kPendCap) / NT;  // keys per thread: element i * NT + t of best | pend
+    constexpr int KB = KC / NT;                // the first KB of them are best-area slots
     auto flush = [&]() {
-        unsigned char* scratch = reinterpret_cast<unsigned char*>(lut + (buf ^ 1) * E);
-        int32_t* hist = reinterpret_cast<int32_t*>(scratch);                  // [256] radix-select digit counts
-        uint16_t* holes = reinterpret_cast<uint16_t*>(hist + 256);            // [KC] slots of the best area that lose their key
-        uint16_t* movers = holes + KC;                                        // [kPendCap] queue entries that stay
         const int n = misc[2];
         const int N = KC + n;                      // entries of the contiguous array best | pend
-        u64* all = best;
-        u64 prefix = 0;                            // digits decided so far (high bytes)
-        int want = a.k;                            // 1-based rank of the wanted key among the candidates
-        int shift = 56;
-        bool unique = false;
-        __syncthreads();
-        for (; shift >= 0; shift -= 8) {
-            hist[t] = 0;
-            __syncthreads();
-            const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-            // (the leading bytes of ordered distances are nearly constant: 64 lanes adding to ONE counter would
-            // serialise in the LDS atomic unit, so a wave whose candidates all share the digit adds once)
-            for (int e0 = 0; e0 < N; e0 += NT) {
-                const int e = e0 + t;
-                int digit = -1;
-                if (e < N) {
-                    const u64 key = all[e];
-                    if ((key & himask) == prefix) digit = (int)((key >> shift) & 255u);
-                }
-                const u64 part = __ballot(digit >= 0);
-                if (part != 0) {
-                    const int src = __builtin_ffsll((long long)part) - 1;
-                    const int d0 = __shfl(digit, src, 64);
-                    const u64 same = __ballot(digit == d0);
-                    if (same == part) { if (lane == src) atomicAdd(&hist[d0], __popcll(part)); }
-                    else if (digit >= 0) atomicAdd(&hist[digit], 1);
-                }
-            }
-            __syncthreads();
-            if (wave == 0) {                       // the digit whose cumulative count reaches `want`
-                const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
-                const int own = c0 + c1 + c2 + c3;
-                int incl = own;
+        if (t == 0) { misc[17] = 0; misc[18] = 0; misc[19] = 0; misc[22] = -1; misc[23] = 0; }
+        hist[t] = 0;
+        hist[256 + t] = 0;
+        u64 kreg[KPT];
 #pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) {
-                    const int o = __shfl_up(incl, sft, 64);
-                    if (lane >= sft) incl += o;
-                }
-                const int before = incl - own;
-                if (before < want && want <= incl) {   // exactly one lane
-                    int r = want - before, d = 0, cnt = c0;
-                    if (r > c0) { r -= c0; d = 1; cnt = c1; if (r > c1) { r -= c1; d = 2; cnt = c2; if (r > c2) { r -= c2; d = 3; cnt = c3; } } }
-                    misc[12] = 4 * lane + d;
-                    misc[13] = r;
-                    misc[14] = cnt;
-                }
-            }
-            __syncthreads();
-            prefix |= (u64)(uint32_t)misc[12] << shift;
-            want = misc[13];
-            if (misc[14] == 1) { unique = true; break; }     // one candidate left: fetch it instead of more passes
+        for (int i = 0; i < KPT; i++) {
+            const int e = i * NT + t;
+            kreg[i] = e < N ? best[e] : kMaxKey;
         }
-        u64 kth = prefix;
-        if (unique && shift > 0) {
-            const u64 himask = ~0ull << shift;
-            for (int e = t; e < N; e += NT) {
-                const u64 key = all[e];
-                if ((key & himask) == prefix) { misc[15] = (int32_t)(uint32_t)key; misc[16] = (int32_t)(uint32_t)(key >> 32); }
-            }
-            __syncthreads();
-            kth = ((u64)(uint32_t)misc[16] << 32) | (uint32_t)misc[15];
-        }
-        // keepers: real keys <= kth (exactly k of them unless fewer than k real keys exist: then kth
-        // is the padding value and every real key stays).  Queue keepers move into the holes of the
-        // best area.
-        if (t == 0) { misc[17] = 0; misc[18] = 0; }
+        u64 kth = kMaxKey;                         // fewer than k real keys: the padding value, every real key stays
         __syncthreads();
-        for (int e = t; e < KC; e += NT) {
-            const u64 key = all[e];
-            if (!(key <= kth && key != kMaxKey)) holes[atomicAdd(&misc[17], 1)] = (uint16_t)e;
+        if (nreal + n >= a.k) {
+            uint32_t mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+            for (int i = 0; i < KPT; i++) {
+                const uint32_t hd = (uint32_t)(kreg[i] >> 32);
+                if (kreg[i] != kMaxKey) { mn = min(mn, hd); mx = max(mx, hd); }
+            }
+            mn = wave_min_u32(mn);
+            mx = ~wave_min_u32(~mx);
+            if (lane == 0) { atomicMin(reinterpret_cast<uint32_t*>(&misc[22]), mn); atomicMax(reinterpret_cast<uint32_t*>(&misc[23]), mx); }
+            __syncthreads();
+            u64 lo = (u64)(uint32_t)misc[22] << 32, hi = ((u64)(uint32_t)misc[23] << 32) | 0xFFFFFFFFull;
+            int want = a.k;                        // 1-based rank of the wanted key among the keys >= lo
+            for (int pass = 0;; pass++) {
+                const u64 width = hi - lo;
+                if (width == 0) { kth = lo; break; }
+                const int s = max(0, 56 - (int)__builtin_clzll(width));      // (width >> s) <= 255
+                int32_t* H = hist + (pass % 3) * 256;
+#pragma unroll
+                for (int i = 0; i < KPT; i++) {
+                    const u64 key = kreg[i];
+                    if (key >= lo && key <= hi) atomicAdd(&H[(int)((key - lo) >> s)], 1);
+                }
+                __syncthreads();
+                // (every wave has left the counters of pass - 1: they become those of pass + 2, needed after the next barrier)
+                hist[((pass + 2) % 3) * 256 + t] = 0;
+                // the bucket whose cumulative count reaches `want`: lane l owns buckets 4l .. 4l+3
+                const int4 c = *reinterpret_cast<const int4*>(H + 4 * lane);
+                const int own = c.x + c.y + c.z + c.w;
+                const int incl = wave_inclusive_sum(own, lane);
+                const int before = incl - own;
+                int r = want - before, d = 0, cnt = c.x;
+                if (r > c.x) { r -= c.x; d = 1; cnt = c.y; if (r > c.y) { r -= c.y; d = 2; cnt = c.z; if (r > c.z) { r -= c.z; d = 3; cnt = c.w; } } }
+                const u64 hit = __ballot(before < want && want <= incl);       // exactly one lane
+                const int src = __builtin_ffsll((long long)hit) - 1;
+                const int b = __builtin_amdgcn_readlane(4 * lane + d, src);
+                want = __builtin_amdgcn_readlane(r, src);
+                cnt = __builtin_amdgcn_readlane(cnt, src);
+                lo += (u64)(uint32_t)b << s;
+                { const u64 top = lo + ((1ull << s) - 1ull); hi = (top >= lo && top < hi) ? top : hi; }     // (top < lo: wrapped)
+                if (s == 0) { kth = lo; break; }
+                if (cnt <= 64) {
+#pragma unroll
+                    for (int i = 0; i < KPT; i++)
+                        if (kreg[i] >= lo && kreg[i] <= hi) small[atomicAdd(&misc[19], 1)] = kreg[i];
+                    __syncthreads();
+                    const u64 mine = lane < cnt ? small[lane] : kMaxKey;
+                    const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+                    int rank = 0;
+                    for (int j = 0; j < cnt; j++) {
+                        const u64 o = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+                        rank += o < mine ? 1 : 0;
+                    }
+                    const u64 m = __ballot(lane < cnt && rank == want - 1);   // exactly one lane
+                    const int sl = __builtin_ffsll((long long)m) - 1;
+                    kth = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)mhi, sl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mlo, sl);
+                    break;
+                }
+            }
         }
-        for (int e = t; e < n; e += NT) {
-            const u64 key = pend[e];
-            if (key <= kth && key != kMaxKey) movers[atomicAdd(&misc[18], 1)] = (uint16_t)e;
+        // keepers: real keys <= kth (exactly k of them unless fewer than k real keys exist: then kth is the padding
+        // value and every real key stays).  A wave counts its holes and its queue keepers in registers and takes its
+        // ranks with one LDS atomic each.
+        u64 hb[KB], mb[KPT - KB];
+        int nh = 0, nm = 0;
+#pragma unroll
+        for (int i = 0; i < KB; i++) { hb[i] = __ballot(!(kreg[i] <= kth && kreg[i] != kMaxKey)); nh += __popcll(hb[i]); }
+#pragma unroll
+        for (int i = KB; i < KPT; i++) { mb[i - KB] = __ballot(kreg[i] <= kth && kreg[i] != kMaxKey); nm += __popcll(mb[i - KB]); }
+        int hbase = 0, mbase = 0;
+        if (lane == 0) { hbase = atomicAdd(&misc[17], nh); mbase = atomicAdd(&misc[18], nm); }
+        hbase = __builtin_amdgcn_readfirstlane(hbase);
+        mbase = __builtin_amdgcn_readfirstlane(mbase);
+        const u64 below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = KB; i < KPT; i++) {
+            if ((mb[i - KB] >> lane) & 1ull) pend[mbase + __popcll(mb[i - KB] & below)] = kreg[i];
+            mbase += __popcll(mb[i - KB]);
         }
         __syncthreads();
         const int nholes = misc[17], nmov = misc[18];
-        for (int e = t; e < nholes; e += NT) best[holes[e]] = e < nmov ? pend[movers[e]] : kMaxKey;
-        __syncthreads();
-        if (t == 0) {
-            misc[2] = 0;
-            misc[3] = (int32_t)(kth == kMaxKey ? __float_as_uint(3.402823466e+38f)
-                                               : __float_as_uint(ordered_to_f32((uint32_t)(kth >> 32))));
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            if ((hb[i] >> lane) & 1ull) {
+                const int j = hbase + __popcll(hb[i] & below);
+                best[i * NT + t] = j < nmov ? pend[j] : kMaxKey;
+            }
+            hbase += __popcll(hb[i]);
         }
+        nreal = KC - nholes + min(nholes, nmov);
+        thr = kth == kMaxKey ? 3.402823466e+38f : ordered_to_f32((uint32_t)(kth >> 32));
+        if (t == 0) misc[2] = 0;
         __syncthreads();
-        thr = __uint_as_float((uint32_t)misc[3]);
     };
 
     float4 t2r[NI];
@@ -256,12 +324,14 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
     // trip's parity, and after the trip's barrier everyone adds the four counts of THAT parity.
     int npend_reg = 0;
     uint32_t trip = 0;
+    bool tripped = false;
     for (int i = 0; i < nlive; i++) {
         const uint32_t len = n_len;
         const float dis0 = n_dis0;
         const uint32_t pos0 = n_pos0;
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + n_off;
-        build_lut16<NI>(lut + buf * E, t, t2r, m2t3);
+        if (i > 0 && !tripped) __syncthreads();                // (an empty list before: no trip barrier has said that everyone is done with the table)
+        build_lut16<NI>(lut, t, t2r, m2t3);
         uint4 cc = c0;
         prefetch(i + 1);
         __syncthreads();
@@ -269,7 +339,7 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
         for (uint32_t j0 = 0; j0 < len; j0 += NT) {
             const uint32_t j = j0 + t;
             const uint4 cn = cp[min(j + NT, len - 1)];
-            const float dis = buf == 0 ? adc16_fixed<0>(cc, dis0, two) : adc16_fixed<1>(cc, dis0, two);
+            const float dis = adc16_fixed<0>(cc, dis0, two);
             const bool pred = j < len && dis <= thr && dis < 3.402823466e+38f;
             const u64 mask = __ballot(pred);
             const int cnt = __popcll(mask);
@@ -288,7 +358,7 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
             if (npend_reg > kPendCap - NT) { flush(); npend_reg = 0; }   // the same decision in every thread
         }
         nscan += len;
-        buf ^= 1;
+        tripped = len > 0;
     }
     flush();
     wg_bitonic_sort<KC>(best, t);                             // the one sort: rows leave in ascending key order
@@ -327,8 +397,8 @@ void launch_scan16_bigk(const ScanArgs& a_in, hipStream_t s) {
     a.nsplit = 1;
     a.xcd_chunk = (int)((a.nq + 7) / 8);
     const int kc = a.k <= 512 ? 512 : 1024;
-    const size_t lutb = (size_t)2 * 4096 * 4;
-    const size_t smem = lutb + (size_t)(kc + kPendCap) * 8 + (size_t)a.nprobe * 24 + 8 + 80 + (size_t)a.nprobe * 2 + 64;
+    const size_t lutb = (size_t)4096 * 4;
+    const size_t smem = lutb + (size_t)(kc + kPendCap) * 8 + 3 * 256 * 4 + 64 * 8 + (size_t)a.nprobe * 24 + 8 + 104 + (size_t)a.nprobe * 2 + 64;
     const bool imi = a.imi_nbits > 0;
     if (kc == 512) { if (imi) launch_bigk_t<512, true>(a, (int)lutb, smem, s); else launch_bigk_t<512, false>(a, (int)lutb, smem, s); }
     else { if (imi) launch_bigk_t<1024, true>(a, (int)lutb, smem, s); else launch_bigk_t<1024, false>(a, (int)lutb, smem, s); }
