@@ -99,3 +99,32 @@ def test_long_lists_every_k_class(k, dup):
     Do, Io = ox.search(xq, nprobe, k, canonical=True)
     assert np.array_equal(bits(D), bits(Do))
     assert np.array_equal(I, Io)
+
+
+@pytest.mark.parametrize("k,dup", [(129, 1), (200, 8), (256, 1), (257, 16), (512, 40), (700, 1), (1024, 8)])
+def test_medium_lists_shared_queue_selection(k, dup):
+    """Lists of 24 .. 1023 codes on average and k > 128: scan16_bigk_kernel (capacities 256 / 512 / 1024) -- one
+    selection per workgroup, the k-th key of a flush found by band-relative bucket counts.  `dup` stores every
+    vector several times: runs of equal distances longer than a 64-key band (the gathered last step), flushes
+    with fewer than k real keys, k > the codes a query sees (padding rows)."""
+    rng = np.random.default_rng(500 + k + dup)
+    d, nlist, M, nb, nq, nprobe = 32, 24, 16, 9600, 48, 9
+    centres = rng.random((5, d)).astype(np.float32)
+    gen = lambda n: (centres[rng.integers(0, 5, n)] + 0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    coarse = gen(nlist)
+    pq = (0.2 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    xb = np.repeat(gen(nb // dup), dup, axis=0)[rng.permutation(nb // dup * dup)]
+    xq = gen(nq)
+    xq[:8] = xb[:8]
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(coarse)
+    g.set_pq_centroids(pq)
+    ox = pyoracle.OracleIndex(d, nlist, M, 8, coarse, pq)
+    g.add(xb)
+    ox.add(xb, None, canonical=True)
+    assert 24 * nlist <= g.ntotal < 1024 * nlist
+    for np_ in (nprobe, 1):                                   # nprobe 1: fewer codes than k for the small lists
+        D, I = g.search(xq, np_, k)
+        Do, Io = ox.search(xq, np_, k, canonical=True)
+        assert np.array_equal(bits(D), bits(Do))
+        assert np.array_equal(I, Io)

@@ -427,8 +427,12 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                     ap.I = h->ws_Ip.as<int64_t>();
                     vlq::launch_scan16(ap, h->stream);
                     vlq::launch_merge_topk(ap.D, ap.I, ni, k, nsplit, a.D, a.I, h->stream);
-                } else if (k > 256) {
-                    vlq::launch_scan16_bigk(a, h->stream);      // one selection per workgroup
+                } else if (k > 256 || (k > 128 && !a.long_lists)) {
+                    // one selection per workgroup.  128 < k <= 256 (round 3, 10 000 queries): bench index (lists of ~700
+                    // codes where probed) k = 200 1.06 -> 0.89 ms, k = 256 1.14 -> 0.90 ms against the per-wave lists of
+                    // scan16_kernel<4>; lists of 3 906 codes 4.01 / 4.14 ms for the pipelined scan16 against 4.56 / 4.59:
+                    // the trip barriers of the shared queue cost more than four private merge networks there
+                    vlq::launch_scan16_bigk(a, h->stream);
                 } else {
                     vlq::launch_scan16(a, h->stream);
                 }

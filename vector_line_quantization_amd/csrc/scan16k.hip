@@ -396,11 +396,12 @@ void launch_scan16_bigk(const ScanArgs& a_in, hipStream_t s) {
     ScanArgs a = a_in;
     a.nsplit = 1;
     a.xcd_chunk = (int)((a.nq + 7) / 8);
-    const int kc = a.k <= 512 ? 512 : 1024;
+    const int kc = a.k <= 256 ? 256 : a.k <= 512 ? 512 : 1024;
     const size_t lutb = (size_t)4096 * 4;
     const size_t smem = lutb + (size_t)(kc + kPendCap) * 8 + 3 * 256 * 4 + 64 * 8 + (size_t)a.nprobe * 24 + 8 + 104 + (size_t)a.nprobe * 2 + 64;
     const bool imi = a.imi_nbits > 0;
-    if (kc == 512) { if (imi) launch_bigk_t<512, true>(a, (int)lutb, smem, s); else launch_bigk_t<512, false>(a, (int)lutb, smem, s); }
+    if (kc == 256) { if (imi) launch_bigk_t<256, true>(a, (int)lutb, smem, s); else launch_bigk_t<256, false>(a, (int)lutb, smem, s); }
+    else if (kc == 512) { if (imi) launch_bigk_t<512, true>(a, (int)lutb, smem, s); else launch_bigk_t<512, false>(a, (int)lutb, smem, s); }
     else { if (imi) launch_bigk_t<1024, true>(a, (int)lutb, smem, s); else launch_bigk_t<1024, false>(a, (int)lutb, smem, s); }
 }
 
