@@ -362,6 +362,37 @@ def test_device_resident_buffers():
     assert np.array_equal(I.cpu().numpy(), Io)
 
 
+@pytest.mark.parametrize("nq", [100, 4096, 5000])
+def test_host_buffers_pageable_and_page_locked(nq):
+    """The reference drivers' calling convention: x / D / I in host memory.  4 096 queries and more: the batch is copied
+    in four chunks, each beside the coarse GEMM of the chunk before; page-locked outputs
+    (GpuResources::getPinnedMemory) are written by the scan kernel itself.  Same rows as the device-resident call, which the oracle checks above."""
+    import torch
+    case = Case("c1_small")
+    g = gpu_index(case)
+    xq = np.concatenate([case.xq] * (1 + nq // case.xq.shape[0]))[:nq]
+    xd = torch.from_numpy(xq).cuda()
+    Dd, Id = g.search(xd, case.nprobe, case.k)
+    torch.cuda.synchronize()
+    Dd, Id = Dd.cpu().numpy(), Id.cpu().numpy()
+    ox = case.oracle_index()
+    Do, Io = ox.search(xq[:64], case.nprobe, case.k, canonical=True)
+    assert np.array_equal(bits(Dd[:64]), bits(Do)) and np.array_equal(Id[:64], Io)
+    D, I = g.search(xq, case.nprobe, case.k)                         # pageable numpy
+    assert np.array_equal(bits(D), bits(Dd)) and np.array_equal(I, Id)
+    xp = torch.from_numpy(xq).pin_memory()
+    Dp = torch.full((nq, case.k), -1.0, dtype=torch.float32).pin_memory()
+    Ip = torch.full((nq, case.k), -7, dtype=torch.int64).pin_memory()
+    for _ in range(2):                                               # second call: the staging buffer is reused
+        g.search(xp.numpy(), case.nprobe, case.k, D=Dp.numpy(), I=Ip.numpy())
+        assert np.array_equal(bits(Dp.numpy()), bits(Dd)) and np.array_equal(Ip.numpy(), Id)
+    # mixed: page-locked distances, pageable labels
+    I2 = np.empty((nq, case.k), np.int64)
+    Dp.fill_(-1.0)
+    g.search(xq, case.nprobe, case.k, D=Dp.numpy(), I=I2)
+    assert np.array_equal(bits(Dp.numpy()), bits(Dd)) and np.array_equal(I2, Id)
+
+
 @pytest.mark.parametrize("k,nparts", [(10, 2), (100, 8), (300, 3)])
 def test_merge_topk(k, nparts):
     """vlq_merge_topk (list-sharded mode): the k smallest over the shards' sorted rows,

@@ -25,3 +25,14 @@ for _ in range(20): xq.copy_(torch.from_numpy(xh))
 torch.cuda.synchronize(); tc = (time.perf_counter() - t0) / 20 * 1e3
 print("device-resident step %.3f ms; host-buffer step %.3f ms (x%.3f); plain pageable H2D of the queries alone %.3f ms; results equal: %s" % (
     td, th, th / td, tc, bool(np.array_equal(Dh, D.cpu().numpy()) and np.array_equal(Ih, I.cpu().numpy()))))
+# page-locked buffers (GpuResources::getPinnedMemory's kind)
+xp = torch.from_numpy(xh).pin_memory(); Dp = torch.empty((10000, 10), dtype=torch.float32).pin_memory(); Ip = torch.empty((10000, 10), dtype=torch.int64).pin_memory()
+xpn, Dpn, Ipn = xp.numpy(), Dp.numpy(), Ip.numpy()
+tp = timeit(lambda: g.search(xpn, 32, 10, D=Dpn, I=Ipn))
+tpd = timeit(lambda: g.search(xpn, 32, 10, D=D, I=I))          # page-locked queries, device results
+tdp = timeit(lambda: g.search(xq, 32, 10, D=Dpn, I=Ipn))        # device queries, page-locked results
+def cp_in(): xq.copy_(xp, non_blocking=True)
+def cp_out(): Dp.copy_(D, non_blocking=True); Ip.copy_(I, non_blocking=True)
+print("page-locked x/D/I %.3f ms (x%.3f); page-locked x only %.3f; page-locked D/I only %.3f; H2D alone %.3f ms; D2H alone %.3f ms; equal: %s" % (
+    tp, tp / td, tpd, tdp, timeit(cp_in), timeit(cp_out),
+    bool(np.array_equal(Dpn, D.cpu().numpy()) and np.array_equal(Ipn, I.cpu().numpy()))))

@@ -22,9 +22,14 @@ int stage_in(vlq_ivfpq_t h, const void* src, size_t bytes, DevBuf& ws, const voi
     return VLQ_OK;
 }
 
-// pick the device-side destination of an output
-int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy) {
-    if (is_device_ptr(dst)) { *dev = dst; *need_copy = false; return VLQ_OK; }
+// pick the device-side destination of an output.  zero_copy != nullptr: page-locked host memory is written by the
+// kernels themselves (the rows cross PCIe while the scan runs; the caller synchronises the stream before returning)
+int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy, bool* zero_copy) {
+    if (zero_copy) *zero_copy = false;
+    void* mapped = nullptr;
+    const int kind = ptr_kind(dst, &mapped);
+    if (kind == 1) { *dev = dst; *need_copy = false; return VLQ_OK; }
+    if (kind == 2 && zero_copy) { *dev = mapped; *need_copy = false; *zero_copy = true; return VLQ_OK; }
     TRY(ws.reserve(bytes));
     *dev = ws.p;
     *need_copy = true;
@@ -863,25 +868,35 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
 // chunked copy-in with the coarse stage chunk by chunk behind it and ONE scan 1.13 ms (1.32x).  A
 // pageable hipMemcpyAsync blocks the host, so nothing can be enqueued behind it without pinning the
 // caller's pages; DESIGN.md section 7.
+// Round 3, page-locked buffers (GpuResources::getPinnedMemory): result rows are written by the scan kernel straight
+// into the caller's memory (free: 0.848 ms against 0.848 device-resident; the D2H copies cost 0.055 ms), the 5 MB of
+// queries cost their 0.105 ms at 51 GB/s.  Copy-in on a second stream was tried twice more with page-locked sources --
+// two halves, each with its own coarse call (0.986 ms against 0.974 unsplit: the copy of the second half does run
+// beside the first GEMM, rocprofv3 --memory-copy-trace, but two half-size GEMM + select pairs cost 190 us against
+// 161 and the event wait 15 us); four chunks beside four partial GEMMs of ONE matrix, one select (1.000 ms) -- and
+// removed: cross-stream event waits cost more than the 50-75 us of copy they hide.  (Polling hipStreamQuery instead of
+// hipStreamSynchronize at the end: 0.977 against 0.984 ms, noise.)
 int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k, float* D,
                      int64_t* I) {
     TRY(check_ready(h, true));
     TRY(check_search_args(h, n, x, nprobe, k, D, I));
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
-    const void* xd;
-    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     TRY(h->ws_keys.reserve((size_t)n * nprobe * 8));
     TRY(h->ws_cdis.reserve((size_t)n * nprobe * 4));
     void *Dd, *Id;
-    bool copyD, copyI;
-    TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
-    TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
+    bool copyD, copyI, zcD, zcI;
+    TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD, &zcD));
+    TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI, &zcI));
+    const void* xd = nullptr;
+    TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     // IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081): quantizer->search, then search_knn_with_key
     TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
     TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
                  (float*)Dd, (int64_t*)Id, 0));
-    return finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8);
+    TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
+    if ((zcD || zcI) && !(copyD || copyI)) HIP_TRY(hipStreamSynchronize(h->stream));    // rows in the caller's memory on return
+    return VLQ_OK;
 }
 
 int vlq_ivfpq_query_tables(vlq_ivfpq_t h, int64_t n, const float* x, int inner_product, float* out) {

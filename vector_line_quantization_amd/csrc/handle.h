@@ -63,6 +63,18 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// 0 = ordinary (pageable) host memory, 1 = device / managed memory, 2 = page-locked host memory that kernels can
+// address (hipHostMalloc / hipHostRegister: what GpuResources::getPinnedMemory hands out); *dev = its device-side address
+inline int ptr_kind(const void* p, void** dev = nullptr) {
+    if (!p) return 0;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return 1;
+    if (attr.type == hipMemoryTypeHost && attr.devicePointer) { if (dev) *dev = attr.devicePointer; return 2; }
+    return 0;
+}
+
 inline bool is_device_ptr(const void* p) {
     if (!p) return false;
     hipPointerAttribute_t attr;
@@ -134,7 +146,7 @@ struct vlq_ivfpq_s {
 namespace vlq_detail {
 int set_dev(vlq_ivfpq_t h);
 int stage_in(vlq_ivfpq_t h, const void* src, size_t bytes, DevBuf& ws, const void** out);
-int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy);
+int stage_out(void* dst, size_t bytes, DevBuf& ws, void** dev, bool* need_copy, bool* zero_copy = nullptr);
 int finish_outputs(vlq_ivfpq_t h, bool copyD, void* D, const void* Dd, size_t bytesD, bool copyI,
                    void* I, const void* Id, size_t bytesI);
 int ensure_term2(vlq_ivfpq_t h);
