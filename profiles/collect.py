@@ -17,7 +17,7 @@ shutil.copy(os.path.join(SRC, "sweep.md"), dst("sweep.md"))
 shutil.copy(one("imi10/**/*kernel_stats.csv"), dst("imi_kernel_stats.csv"))
 shutil.copy(one("imi14/**/*kernel_stats.csv"), dst("imi14_kernel_stats.csv"))
 shutil.copy(one("vlq/**/*kernel_stats.csv"), dst("vlq_kernel_stats.csv"))
-for extra in ("vlq_fp16.log", "sched_ab.txt", "host_buffers.txt"):
+for extra in ("vlq_fp16.log", "sched_ab.txt", "host_buffers.txt", "slices.txt"):
     if os.path.exists(os.path.join(SRC, extra)):
         shutil.copy(os.path.join(SRC, extra), dst(extra if extra.endswith(".txt") else extra.replace(".log", ".txt")))
 with open(dst("long_lists.txt"), "w") as f:

@@ -42,6 +42,8 @@ echo "imi/vlq done" >&2
   for K in 10 100; do DIM=96 NPROBE=128 K=$K $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu; done
   NPROBE=64 K=10 $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu
 } > $OUT/long_lists.txt
-$T 200 python $REPO/tools/large_k.py 2>/dev/null | grep total > $OUT/large_k.txt
+KS=100,128,129,200,256,257,512,1000 $T 200 python $REPO/tools/large_k.py 2>/dev/null | grep total > $OUT/large_k.txt
+$T 200 python $REPO/tools/slice_stages.py 2>/dev/null | grep "^nq" > $OUT/slices.txt
+$T 200 python $REPO/tools/host_buffers.py 2>/dev/null | grep -v "amdgpu\|^\[bench\]" > $OUT/host_buffers.txt
 fi
 echo "all done" >&2
