@@ -478,9 +478,9 @@ def test_nearest_centroid_without_distance_matrix(nlist, d):
     assert np.array_equal(assign, keys[:, 0])
 
 
-@pytest.mark.parametrize("k", [300, 1000])
+@pytest.mark.parametrize("k", [200, 300, 1000])
 def test_multi_index_with_workgroup_selection(k):
-    """Inverted multi-index + table type 2 through the one-selection-per-workgroup kernel (k > 256,
+    """Inverted multi-index + table type 2 through the one-selection-per-workgroup kernel (k > 128,
     scan16_bigk_kernel<.., IMI>): lists long enough for the per-probe table kernel, ties from duplicated
     vectors, against the oracle."""
     from oracle.pyoracle import OracleIndex
