@@ -139,7 +139,10 @@ int vlq_ivfpq_set_float16_tables(vlq_ivfpq_t h, int enable);
 int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode);
 
 /* IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) = GpuIndexIVFPQ::search.
- * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024. */
+ * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024.
+ * Host D / I: the call returns with the rows in place.  PAGE-LOCKED host D / I (hipHostMalloc / hipHostRegister:
+ * what GpuResources::getPinnedMemory hands out, gpu/GpuResources.h:40) are written by the scan kernel itself --
+ * no staging buffer, no copy-out; pageable ones are staged through device memory and copied. */
 int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k,
                      float* D, int64_t* I);
 
