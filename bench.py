@@ -721,7 +721,13 @@ def main():
                      "frac_measured": (traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and scan_ms > 0) else None,
                      "algorithmic_bytes": code_bytes,
                      "lut_bytes_separate": lut_bytes,
-                     "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0},
+                     "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
+                     # what actually bounds this kernel: one random 32-bit LDS gather per code byte.  Peak = the measured
+                     # gather rate of the LDS pipe (tools/micro/lds_gather.hip: 12.2 lanes per clock and CU at 16 waves per
+                     # CU, 2.4 GHz nominal, 256 CUs) -- reported beside the HBM fraction the contract asks for
+                     "lds_gather": {"achieved_per_clock_cu": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 if scan_ms > 0 else 0.0,
+                                    "peak_per_clock_cu": 12.2,
+                                    "frac": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 / 12.2 if scan_ms > 0 else 0.0}},
         "stage_ms": {"coarse": prof_all["coarse_ms"] / 5, "tables": prof_all["tables_ms"] / 5,
                      "scan": prof_all["scan_ms"] / 5, "note": "from 5 extra untimed steps with every stage instrumented"},
     }
