@@ -138,6 +138,19 @@ int vlq_ivfpq_set_float16_tables(vlq_ivfpq_t h, int enable);
  * Replaces nothing in the reference (its CPU loop has no such choice). */
 int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode);
 
+/* Float16 screen of the coarse stage -- SPEED ONLY, results are identical with and without it (csrc/coarse_screen.hip):
+ * batches of 2048 queries and more on flat coarse quantizers of 256 .. 8192 centroids (d <= 128, nprobe 2 .. 64) first get an
+ * APPROXIMATE distance matrix from half copies of queries and centroids; a rigorous bound on |approximate - exact| keeps
+ * every column that can still be among a row's nprobe nearest, and only those get the exact fp32 distance of the matrix
+ * path (the same k-ascending fmaf chain), then the same (distance, column) selection.  Rows the bound cannot decide are
+ * done exactly in full; an index where that happens to more than 0.5 % of the rows drops the screen by itself.
+ *   mode 0: off (f32 MFMA distance matrix for every batch), 1: on where the shape allows (the default).
+ * vlq_ivfpq_coarse_screen_state: *enabled = the screen is (still) in use for this index, *rows = rows that went through it,
+ * *undecided = rows it handed to the exact path (as of the last batch whose counters have reached the host).
+ * Replaces nothing in the reference (knn_L2sqr computes every distance, utils.cpp:935-946). */
+int vlq_ivfpq_set_coarse_screen(vlq_ivfpq_t h, int mode);
+int vlq_ivfpq_coarse_screen_state(vlq_ivfpq_t h, int* enabled, uint64_t* rows, uint32_t* undecided);
+
 /* IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) = GpuIndexIVFPQ::search.
  * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024.
  * Host D / I: the call returns with the rows in place.  PAGE-LOCKED host D / I (hipHostMalloc / hipHostRegister:

@@ -1,0 +1,87 @@
+"""GPU: the float16 screen of the coarse stage (csrc/coarse_screen.hip; include/vlq_ivfpq.h vlq_ivfpq_set_coarse_screen)
+never shows in a result: batches of 2048 queries and more against the oracle's coarse assignment -- knn_L2sqr's
+(distance, column) order (utils.cpp:884, :935-946; Heap.h) -- bit for bit, on every row-size class, with runs of exact
+ties, on data that defeat the screen's error bound (every row is then done exactly and the index drops the screen by
+itself), with queries outside the half range and with queries that are not numbers."""
+import numpy as np
+import pytest
+
+import vector_line_quantization_amd as vlq
+from oracle.pyoracle import OracleIndex
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+NQ = 2200          # >= 2048: the screened path; 2200 = 17 row blocks of 128 + 24 rows
+
+
+def make(nlist, d, rng, offset=0.0, spread=1.0):
+    M = 4 if d % 4 == 0 and d >= 4 else 1
+    cent = (offset + spread * rng.random((nlist, d))).astype(np.float32)
+    cent[nlist // 2:nlist // 2 + 40] = cent[3]              # a run of exact ties
+    pq = rng.random((M, 256, d // M)).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    return g, OracleIndex(d, nlist, M, 8, cent, pq), cent
+
+
+@pytest.mark.parametrize("nlist,d,nprobe,decides", [(256, 16, 8, True), (1024, 64, 32, True), (2048, 100, 17, True),
+                                                    (4096, 128, 32, True), (4096, 96, 2, True),
+                                                    # uniform data, many centroids, few dimensions: the distances of a row are
+                                                    # so dense around the 64th that the bound keeps more columns than a row's
+                                                    # list holds -- those rows are done exactly in full
+                                                    (8192, 32, 64, False)])
+def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
+    rng = np.random.default_rng(nlist + d + nprobe)
+    g, ox, cent = make(nlist, d, rng)
+    xq = rng.random((NQ, d)).astype(np.float32)
+    xq[:64] = cent[rng.integers(0, nlist, 64)]               # queries ON centroids: distance 0 and, for the tie run, ties at 0
+    cd, keys = g.coarse_search(xq, nprobe)
+    en, rows, und = g.coarse_screen_state()
+    assert rows == NQ                                        # the screen ran ...
+    assert (en and und == 0) if decides else und > 0          # ... and decided every row, where the data let it
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+    g.set_coarse_screen(0)                                    # and the matrix path gives the same (the switch is speed only)
+    cd0, keys0 = g.coarse_search(xq, nprobe)
+    assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
+
+
+def test_data_that_defeat_the_bound_are_done_exactly_and_drop_the_screen():
+    """Centroids 1000 + noise: |q| |c| is 10^7 times the spread of the distances, the bound keeps every column."""
+    rng = np.random.default_rng(5)
+    nlist, d, nprobe = 512, 32, 16
+    g, ox, cent = make(nlist, d, rng, offset=1000.0, spread=0.01)
+    xq = (1000.0 + 0.01 * rng.random((NQ, d))).astype(np.float32)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    for it in range(3):
+        cd, keys = g.coarse_search(xq, nprobe)
+        assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso), it
+    en, rows, und = g.coarse_screen_state()
+    assert not en and und > 0 and rows <= 2 * NQ              # dropped after the first batch's counters reached the host
+
+
+def test_queries_outside_the_half_range_and_nan_rows():
+    rng = np.random.default_rng(6)
+    nlist, d, nprobe = 1024, 32, 8
+    g, ox, cent = make(nlist, d, rng)
+    xq = rng.random((NQ, d)).astype(np.float32)
+    xq[100:105] *= 1.0e6                                      # |q_i| * scale > 65504: flagged rows, exact path
+    xq[500, 3] = np.float32(3.0e38)                           # squared norm overflows to inf
+    cd, keys = g.coarse_search(xq, nprobe)
+    ok = np.ones(NQ, bool)
+    ok[500] = False
+    cdo, keyso = ox.coarse_search(xq[ok], nprobe, canonical=True)
+    assert np.array_equal(bits(cd[ok]), bits(cdo)) and np.array_equal(keys[ok], keyso)
+    en, rows, und = g.coarse_screen_state()
+    assert en and 5 <= und <= 8                               # the flagged rows (and the overflowing one), not the rest;
+                                                              # under 0.5 % of the batch: the screen stays
+    # rows that are not numbers: whatever the matrix path returns for them, the screened path returns too
+    xq[700, 0] = np.nan
+    xq[701] = np.inf
+    cd1, keys1 = g.coarse_search(xq, nprobe)
+    g.set_coarse_screen(0)
+    cd0, keys0 = g.coarse_search(xq, nprobe)
+    assert np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(keys1, keys0)

@@ -178,6 +178,41 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
         HIP_TRY(hipGetLastError());
         return VLQ_OK;
     }
+    if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
+        (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
+        h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
+    // (below ~2000 rows the screen's five short kernels cost more than the matrix path's two: 1250 rows 46 against 40 us)
+    if (!direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_screen && h->screen_ok && n >= 2048 &&
+        vlq::coarse_screen_shape_ok(h->nlist, h->d, nprobe)) {
+        if (!h->screen_cnt_host) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
+            *h->screen_cnt_host = 0;
+            TRY(h->ws_screen_cnt.reserve(8));
+            HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream));
+        }
+        // float16 screen (coarse_screen.hip): approximate matrix -> kept columns -> exact fmaf chains -> exact select
+        const int dp = (h->d + 15) / 16 * 16;
+        TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
+        TRY(h->ws_xflags.reserve((size_t)n));
+        static const bool screen_stats = getenv("VLQ_SCREEN_STATS") != nullptr;       // kept columns per row, printed at destroy
+        if (screen_stats && !h->ws_kept.p) {
+            TRY(h->ws_kept.reserve(16));
+            HIP_TRY(hipMemsetAsync(h->ws_kept.p, 0, 16, h->stream));
+        }
+        TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
+        vlq::launch_screen_row_prep(x_dev, n, h->d, h->screen_scale, h->ws_qn.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
+        vlq::launch_screen_to_half(x_dev, n, h->d, h->screen_scale, h->ws_xh.p, nullptr, h->stream);
+        vlq::launch_coarse_screened(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->coarse_h.p,
+                                    h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_dist.as<float>(), h->ws_cand.p, n, h->nlist, h->d, nprobe,
+                                    h->screen_scale, h->screen_cmax, cdis_dev, keys_dev,
+                                    h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
+                                    h->stream);
+        h->screen_rows_seen += (uint64_t)n;
+        HIP_TRY(hipMemcpyAsync(h->screen_cnt_host, h->ws_screen_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
+        h->screen_rows_copied = h->screen_rows_seen;
+        HIP_TRY(hipGetLastError());
+        return VLQ_OK;
+    }
     if (direct) {
         vlq::launch_coarse_distances_direct(x_dev, h->coarse.as<float>(), h->ws_dist.as<float>(), n,
                                             h->nlist, h->d, h->stream);
@@ -535,6 +570,7 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
         const int m = atoi(e);
         if (m >= 0 && m <= 2) h->scan_schedule = m;
     }
+    if (const char* e = getenv("VLQ_COARSE_SCREEN")) h->coarse_screen = atoi(e);   // 0: f32 MFMA matrix path everywhere (A/B)
     if (const char* e = getenv("VLQ_COARSE_FILTER")) h->coarse_filter = atoi(e);   // 1: filtered coarse stage (A/B; slower)
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
     int rc = h->stats.reserve(16);
@@ -566,6 +602,12 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi};
     for (auto b : bufs) b->release();
+    if (h->screen_cnt_host) (void)hipHostFree(h->screen_cnt_host);
+    if (h->ws_kept.p) {
+        unsigned long long kept = 0;
+        (void)hipMemcpy(&kept, h->ws_kept.p, 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[vlq] coarse screen: %llu columns kept in total\n", kept);
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -652,9 +694,37 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_rank = false;
+    h->screen_ok = false;
     if (h->nlist <= (1 << 17)) {      // O(nlist * d * log nlist) host work; larger indexes keep the list-id order
         std::vector<float> hc((size_t)h->nlist * h->d);
         HIP_TRY(hipMemcpy(hc.data(), h->coarse.p, bytes, hipMemcpyDeviceToHost));
+        // float16 screen of the coarse stage: power-of-two scale from the largest |component|, largest norm (rounded up)
+        {
+            double amax = 0.0, nmax = 0.0;
+            bool finite = true;
+            for (int i = 0; i < h->nlist; i++) {
+                double nn = 0.0;
+                for (int c = 0; c < h->d; c++) {
+                    const double v = hc[(size_t)i * h->d + c];
+                    finite = finite && std::isfinite(v);
+                    amax = std::max(amax, std::fabs(v));
+                    nn += v * v;
+                }
+                nmax = std::max(nmax, nn);
+            }
+            h->screen_ok = false;
+            if (finite && amax > 0.0 && amax < 1e30 && h->d <= 128) {
+                int e = 0;
+                (void)std::frexp(16384.0 / amax, &e);            // 16384 / amax = m * 2^e, m in [0.5, 1)
+                h->screen_scale = std::ldexp(1.f, std::max(-100, std::min(100, e - 1)));     // s * amax <= 16384
+                h->screen_cmax = (float)(std::sqrt(nmax) * 1.0001);
+                const int dp = (h->d + 15) / 16 * 16;
+                TRY(h->coarse_h.reserve((size_t)((h->nlist + 127) / 128 * 128) * dp * 2));
+                vlq::launch_screen_to_half(h->coarse.as<float>(), h->nlist, h->d, h->screen_scale, h->coarse_h.p, nullptr, h->stream);
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                h->screen_ok = true;
+            }
+        }
         std::vector<int> rank;
         spatial_list_rank(hc.data(), h->nlist, h->d, rank);
         TRY(h->list_rank.reserve((size_t)h->nlist * sizeof(int)));
@@ -743,6 +813,27 @@ int vlq_ivfpq_set_float16_tables(vlq_ivfpq_t h, int enable) {
     if (enable && !(h->M == 16 && h->ksub == 256))
         return fail(VLQ_ERR_UNSUPPORTED, "float16 look-up tables are built for 16 x 8-bit codes only");
     h->fp16_tables = enable != 0;
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_set_coarse_screen(vlq_ivfpq_t h, int mode) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (mode != 0 && mode != 1) return fail(VLQ_ERR_INVALID, "coarse screen mode %d (0 = off, 1 = on)", mode);
+    h->coarse_screen = mode;
+    if (mode) { h->screen_rows_seen = h->screen_rows_copied = 0; if (h->screen_cnt_host) *h->screen_cnt_host = 0; }
+    if (mode && h->ws_screen_cnt.p) { TRY(set_dev(h)); HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream)); }
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_coarse_screen_state(vlq_ivfpq_t h, int* enabled, uint64_t* rows, uint32_t* undecided) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (h->screen_cnt_host) { TRY(set_dev(h)); HIP_TRY(hipStreamSynchronize(h->stream)); }     // the mirror is up to date after this
+    if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
+        (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
+        h->coarse_screen = 0;
+    if (enabled) *enabled = (h->coarse_screen && h->screen_ok) ? 1 : 0;
+    if (rows) *rows = h->screen_rows_seen;
+    if (undecided) *undecided = h->screen_cnt_host ? *h->screen_cnt_host : 0u;
     return VLQ_OK;
 }
 

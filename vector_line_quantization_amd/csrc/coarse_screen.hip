@@ -1,0 +1,441 @@
+// Coarse assignment with a float16 SCREEN in front of the exact fp32 arithmetic (round 3).
+//
+// The exact stage -- knn_L2sqr's (|x|^2 + |y|^2) - 2 <x, y> (utils.cpp:884) with the inner products accumulated over
+// k = 0, 1, 2, ... in fp32, what the f32 MFMA distance kernel of kernels.hip computes -- spends 120 us of the 150 us
+// coarse stage of the bench batch on 10 GFLOP of f32 MFMA whose results are, all but nprobe of 4096 per row, thrown
+// away.  Here the whole matrix is first computed APPROXIMATELY from float16 copies of the queries and centroids
+// (v_mfma_f32_32x32x16_f16: 16 x the f32 MFMA rate, so that kernel is bound by its 164 MB of output), every column
+// that can still belong to the row's nprobe nearest is kept -- with a rigorous bound on |approximate - exact|, below
+// -- and only the kept columns (nprobe + a few) get their EXACT distance, as a k-ascending fmaf chain: bit for bit the
+// value of the f32 MFMA kernel.  The selection over the kept (distance, column) keys is the exact stage's.  Same keys,
+// same distances, same tie order as the matrix path; which columns were screened out never shows.
+//
+// Bound.  q~ = half(s q), c~ = half(s c) with s a power of two chosen from max |c_ij| (round to nearest:
+// |x~ - s x| <= 2^-11 |s x| + 2^-25, the second term covers the subnormal range; a query component that overflows
+// sends its row to the exact path).  The f16 products are exact in fp32 and the MFMA accumulates 128 of them in fp32
+// (error <= 2^-16 of their absolute sum, generously).  With |q|, |c| the Euclidean norms,
+//     |ip~ / s^2 - <q, c>|  <=  (2^-10 + 2^-16 + 2^-20) |q| |c|  +  2^-25 sqrt(d) (|q| + |c|) / s
+// (Cauchy-Schwarz on sum |q_i c_i| and on sum |c_i|).  The exact stage's own fp32 value differs from the real-number
+// distance by at most 2^-15 (|q| + |c|)^2 (128-term fmaf chain, the two norms, three more roundings).  Hence
+//     |approximate - exact|  <=  delta(q) := 1.04 * 2^-9 |q| C + 2^-24 sqrt(d) (|q| + C) / s + 2^-14 (|q| + C)^2,
+// C = the largest centroid norm.  Let cut >= the nprobe-th smallest approximate distance of the row.  nprobe columns
+// have exact distance <= cut + delta, so the nprobe-th smallest EXACT distance is <= cut + delta, and a column whose
+// approximate distance exceeds cut + 2 delta has exact distance > cut + delta: it cannot be among the nprobe nearest,
+// nor tie with the nprobe-th.  Rows where that test keeps fewer than nprobe or more than 512 columns (NaN / infinite
+// input, degenerate data) are recomputed in full by the same fmaf chains.
+#include <algorithm>
+#include <cmath>
+
+#include "kernels.h"
+#include "sse_order.cuh"
+#include "wave_topk.cuh"
+
+namespace vlq {
+
+namespace {
+
+#define FLT_MAX_F 3.402823466e+38f
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// x [n][d] -> half(scale * x) in the MFMA's operand order: rows in blocks of 32, components in steps of 16; block
+// (row / 32, ks) is 1 KB = lane (r = row % 32, h = (k % 16) / 8) x 8 halves, so a wave's operand load of one block is
+// one contiguous KB.  Rows n .. n_pad - 1 are zero.  One thread per (row, 8 components): 32-byte reads, 16-byte writes.
+// flags[row] = 1 where a component leaves the half range or is not a number (flags != nullptr: zeroed by the launcher).
+__global__ void screen_to_half_kernel(const float* __restrict__ x, int64_t n, int64_t n_pad, int d, int ks_n, float scale,
+                                      _Float16* __restrict__ out, unsigned char* __restrict__ flags) {
+    const int gpr = 2 * ks_n;                                  // 8-component groups per row
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_pad * gpr) return;
+    const int64_t row = e / gpr;
+    const int grp = (int)(e % gpr), ks = grp >> 1, h = grp & 1;
+    h16x8 v;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = 8 * grp + i;
+        const float f = (row < n && k < d) ? __fmul_rn(scale, x[row * d + k]) : 0.f;
+        bad = bad || !(fabsf(f) <= 65504.f);                   // also true for NaN
+        v[i] = (_Float16)f;
+    }
+    *reinterpret_cast<h16x8*>(out + (((row >> 5) * ks_n + ks) * 64 + h * 32 + (row & 31)) * 8) = v;
+    if (bad && flags) flags[row] = 1;                          // (same value from every writer)
+}
+
+// approximate distances: out[row][col] = (qn[row] + cn[col]) - 2 * <q~, c~> / s^2.  A wave owns a 64 x 64 tile and
+// takes its operands straight from global memory in the MFMA's own layout (lane (r, h): row / column r of a 32-block,
+// components 16 ks + 8 h .. + 7 = one 16-byte load): no LDS, no barrier.  The kernel is bound by the matrix it writes.
+template <int KS>
+__global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
+                                                              const float* __restrict__ qn, const float* __restrict__ cn,
+                                                              _Float16* __restrict__ out, int64_t nq, int nlist, float inv_s2,
+                                                              float sd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + (wave >> 1) * 64;
+    const int col0 = blockIdx.y * 128 + (wave & 1) * 64;
+    if (col0 >= nlist) return;                                 // nlist % 64 == 0: a 64-column tile is whole or absent
+    h16x8 a[2][KS], b[2][KS];             // blocked operand order (screen_to_half_kernel): one contiguous KB per load
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const h16x8* src = reinterpret_cast<const h16x8*>(Qh) + ((row0 >> 5) + rb) * (KS * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) a[rb][ks] = src[ks * 64];
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const h16x8* src = reinterpret_cast<const h16x8*>(Ch) + (int64_t)((col0 >> 5) + cb) * (KS * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) b[cb][ks] = src[ks * 64];
+    }
+    float qnr[2][16];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int64_t row = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            qnr[rb][reg] = qn[row < nq ? row : nq - 1];
+        }
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            f32x16 acc;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][ks], b[cb][ks], acc, 0, 0, 0);
+            // lane (r, h) holds column r of rows 8g + 4h + i (register 4g + i): a 4 x 4 transpose inside each lane quad
+            // (two DPP exchange steps) turns that into one row x 4 consecutive columns = one 16-byte store
+            const float cnv = cn[col0 + cb * 32 + r];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    v[i] = __fsub_rn(__fadd_rn(qnr[rb][4 * g + i], cnv), __fmul_rn(2.f, __fmul_rn(acc[4 * g + i], inv_s2)));
+                {
+                    const bool odd = lane & 1;
+                    float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
+                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, false));
+                    if (odd) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+                }
+                {
+                    const bool up = lane & 2;
+                    float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3];
+                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x4E, 0xf, 0xf, false));
+                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xf, 0xf, false));
+                    if (up) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
+                }
+                // (rows past nq land in the matrix's padding: the caller sizes it to whole 128-row blocks)
+                // stored as half(sd * value): the matrix is what this kernel and the next are bound by.  Values beyond the
+                // half range become +inf and are never kept (sd is chosen so that the range covers 4 C^2).
+                const int64_t row = row0 + rb * 32 + 8 * g + 4 * h + (r & 3);
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                h16x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; i++) hv[i] = (_Float16)__fmul_rn(sd, v[i]);
+                *reinterpret_cast<h16x4*>(out + row * nlist + col0 + cb * 32 + (r & ~3)) = hv;
+            }
+        }
+}
+
+// exact distance of (query row staged in LDS, centroid col): the fmaf chain of the f32 MFMA kernel over k = 0, 1, 2, ...,
+// utils.cpp:884's formula.  The centroid row is fetched 64 components at a time (16 outstanding 16-byte loads per lane:
+// every lane reads a different row, and one load per chain step would pay its latency 32 times).
+__device__ __forceinline__ float exact_distance(const float* qrow, const float* __restrict__ cj, int d, float qnv, float cnv) {
+    float ip = 0.f;
+    int k = 0;
+    for (; k + 64 <= d; k += 64) {
+        float4 cv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) cv[u] = *reinterpret_cast<const float4*>(cj + k + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const float4 qv = *reinterpret_cast<const float4*>(qrow + k + 4 * u);
+            ip = __fmaf_rn(qv.x, cv[u].x, ip);
+            ip = __fmaf_rn(qv.y, cv[u].y, ip);
+            ip = __fmaf_rn(qv.z, cv[u].z, ip);
+            ip = __fmaf_rn(qv.w, cv[u].w, ip);
+        }
+    }
+    for (; k + 4 <= d; k += 4) {
+        const float4 qv = *reinterpret_cast<const float4*>(qrow + k);
+        const float4 cv = *reinterpret_cast<const float4*>(cj + k);
+        ip = __fmaf_rn(qv.x, cv.x, ip);
+        ip = __fmaf_rn(qv.y, cv.y, ip);
+        ip = __fmaf_rn(qv.z, cv.z, ip);
+        ip = __fmaf_rn(qv.w, cv.w, ip);
+    }
+    for (; k < d; k++) ip = __fmaf_rn(qrow[k], cj[k], ip);
+    return __fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip));
+}
+
+// squared norms in fvec_norm_L2sqr's order (norm_sse_order: what the matrix path uses) and the half-range flag of a
+// row, one thread per row (the norm's additions are sequential)
+__global__ void screen_row_prep_kernel(const float* __restrict__ x, int64_t n, int d, float scale, float* __restrict__ norms,
+                                       unsigned char* __restrict__ flags) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const float* xr = x + row * d;
+    bool bad = false;
+    norms[row] = norm_sse_order([&](int c) {
+        const float v = xr[c];
+        bad = bad || !(fabsf(__fmul_rn(scale, v)) <= 65504.f);      // also true for NaN
+        return v;
+    }, d);
+    flags[row] = bad ? 1 : 0;
+}
+
+constexpr int kKeepCap = 256;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
+
+// one wave per row: the row of approximate distances in registers, cut = nprobe-th smallest of the 64 lane minima,
+// columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
+template <int NV>
+__global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
+                                                                 const float* __restrict__ qn, const unsigned char* __restrict__ flags,
+                                                                 float cmax, float c_sub, float inv_sd, uint16_t* __restrict__ keep,
+                                                                 uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // whole wave; no workgroup barrier below
+    const float qnv = qn[q];
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const h16x4* row4 = reinterpret_cast<const h16x4*>(dist + q * nlist);
+    const int n4 = nlist >> 2;
+    float4 v[NV];                               // the stored halves, still scaled by sd
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const h16x4 hv = row4[min(u * 64 + lane, n4 - 1)];      // clamped; masked below
+        v[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+    }
+    float mn = FLT_MAX_F;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        if (u * 64 + lane >= n4) v[u] = make_float4(FLT_MAX_F, FLT_MAX_F, FLT_MAX_F, FLT_MAX_F);
+        mn = fminf(mn, fminf(fminf(v[u].x, v[u].y), fminf(v[u].z, v[u].w)));
+    }
+    const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
+    const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));      // scaled by sd, rounded to half
+    // delta(q), inflated: every factor rounded up generously (the bound is what exactness rests on)
+    const float qnorm = __fmul_rn(sqrtf(fmaxf(qnv, 0.f)), 1.0001f);
+    const float sum = __fadd_rn(qnorm, cmax);
+    const float delta = __fmul_rn(1.001f, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(0.00203125f /* 1.04 * 2^-9 */, qnorm), cmax),
+                                                              __fmul_rn(c_sub, sum)),
+                                                    __fmul_rn(6.103515625e-05f /* 2^-14 */, __fmul_rn(sum, sum))));
+    // a stored value w stands for an approximate distance within 2^-11 |w| / sd (+ the subnormal step) of x = w / sd: a column
+    // is kept iff the smallest distance its stored value allows is <= the largest the cut's allows + 2 delta, i.e. iff
+    // x - eps |x| - sub <= thr.  For thr + sub >= 0 that is x <= (thr + sub) / (1 - eps) (every negative x passes), otherwise
+    // x <= (thr + sub) / (1 + eps): ONE compare per element against T (rounded up), in the stored domain.
+    const float cut = __fmul_rn(inv_sd, cut_s);
+    const float sub = __fmul_rn(inv_sd, 6.0e-8f /* > 2^-24, the subnormal half step */);
+    const float thr = __fadd_rn(__fadd_rn(__fadd_rn(cut, __fmul_rn(0.000489f /* > 2^-11 */, fabsf(cut))), sub), __fmul_rn(2.0002f, delta));
+    const float ts = __fadd_rn(thr, sub);
+    const float tx = ts >= 0.f ? __fmul_rn(ts, 1.00049f /* > 1 / (1 - eps) */) : __fmul_rn(ts, 0.99951f /* < 1 / (1 + eps): towards 0 */);
+    // back to the stored domain, rounded up (1 / inv_sd is the power of two sd: exact)
+    const float T = __fmul_rn(__fadd_rn(tx, __fmul_rn(1e-6f, fabsf(tx))), 1.f / inv_sd);
+    const bool undecided = !(thr < FLT_MAX_F) || !(T < FLT_MAX_F) || flags[q];       // NaN / infinite bound, or a query outside the half range
+    // kept columns: a ballot per register component (most are empty: ~nprobe + 20 of the row's elements pass)
+    uint16_t* out = keep + q * kKeepCap;
+    int total = 0;
+    auto take = [&](float w, uint32_t col) __attribute__((always_inline)) {
+        const bool p = w <= T;                               // false for NaN and for +inf (T is finite)
+        const u64 m = __ballot(p);
+        if (m != 0) {
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (p && pos < kKeepCap) out[pos] = (uint16_t)col;
+            total += __popcll(m);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const uint32_t c0 = (uint32_t)(4 * (u * 64 + lane));
+        take(v[u].x, c0 + 0);
+        take(v[u].y, c0 + 1);
+        take(v[u].z, c0 + 2);
+        take(v[u].w, c0 + 3);
+    }
+    const bool exact_row = undecided || total > kKeepCap || total < nprobe;
+    if (lane == 0) {
+        nkeep[q] = exact_row ? (uint16_t)0xffff : (uint16_t)total;
+        if (exact_row && exact_rows) atomicAdd(exact_rows, 1u);
+    }
+}
+
+// one wave per row: exact distances of the kept columns -- a lane owns one column and runs the f32 MFMA kernel's fmaf
+// chain over k = 0, 1, 2, ... (utils.cpp:884's formula around it) -- and the exact (distance, column) selection.  The
+// centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's 64-byte piece (a lane reading
+// its own row would touch 64 cache lines per load instruction), the owner reads its row back component by component
+// (rows padded to 20 floats: 16-byte LDS accesses both ways); the next chunk's pieces are requested before the current one is used.
+__global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t* __restrict__ keep, const uint16_t* __restrict__ nkeep,
+                                                                  int64_t nq, int nlist, int nprobe, float* __restrict__ cdis,
+                                                                  int64_t* __restrict__ keys, const float* __restrict__ Q,
+                                                                  const float* __restrict__ Cn, const float* __restrict__ qn,
+                                                                  const float* __restrict__ cn, int d,
+                                                                  unsigned long long* __restrict__ kept_total) {
+    __shared__ u64 queue[4][64];
+    __shared__ uint16_t cand[4][kKeepCap];
+    __shared__ __attribute__((aligned(16))) float qrow[4][128];
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * 20];      // rows padded to 20 floats: 16-byte accesses both ways
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // whole wave; no workgroup barrier below
+    // one round trip for everything the row needs first: the count, the whole (fixed-size) list, the query, its norm
+    const int nk = nkeep[q];
+    uint16_t kc[kKeepCap / 64];
+#pragma unroll
+    for (int u = 0; u < kKeepCap / 64; u++) kc[u] = keep[q * kKeepCap + u * 64 + lane];
+    const float q0 = lane < d ? Q[q * d + lane] : 0.f, q1 = lane + 64 < d ? Q[q * d + lane + 64] : 0.f;
+    const float qnv = qn[q];
+    const bool exact_row = nk == 0xffff;
+    const int total = exact_row ? 0 : nk;
+#pragma unroll
+    for (int u = 0; u < kKeepCap / 64; u++) cand[wave][u * 64 + lane] = kc[u];
+    qrow[wave][lane] = q0;
+    qrow[wave][lane + 64] = q1;
+    WaveSelect<1> sel;
+    sel.init(nprobe, queue[wave], lane);
+    __builtin_amdgcn_wave_barrier();
+    if (!exact_row) {
+        float* st = stage[wave];
+        const int nch = (d + 15) >> 4;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int ncand = min(64, total - c0);
+            const bool valid = lane < ncand;
+            const uint32_t col = valid ? cand[wave][c0 + lane] : 0u;
+            const float cnv = cn[col];             // (in flight with the pieces)
+            // pieces of 4 chunks (64 components) are in flight at a time: a load's latency here is ~2 us, the chain
+            // of one chunk takes a tenth of that
+            float4 piece[4][4];
+            // the four rows this lane helps to fetch (lanes 4a .. 4a+3: row a + 16 j), their pieces of a chunk 64 bytes apart
+            const float* rp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ci = (lane >> 2) + 16 * j;
+                rp[j] = Cn + (size_t)(ci < ncand ? cand[wave][c0 + ci] : cand[wave][c0]) * d + 4 * (lane & 3);
+            }
+            auto fetch = [&](int ch, float4 (&dst)[4]) __attribute__((always_inline)) {
+                const bool ld = 16 * ch + 4 * (lane & 3) < d;        // (rows past ncand read row 0 of the batch: never used)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    dst[j] = ld ? *reinterpret_cast<const float4*>(rp[j] + 16 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            float ip = 0.f;
+            for (int ch0 = 0; ch0 < nch; ch0 += 4) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) fetch(ch0 + c4, piece[c4]);      // (chunks past d load nothing)
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    const int ch = ch0 + c4;
+                    if (ch < nch) {                    // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            *reinterpret_cast<float4*>(st + ((lane >> 2) + 16 * j) * 20 + 4 * (lane & 3)) = piece[c4][j];
+                        __builtin_amdgcn_wave_barrier();
+                        const float* mine = st + lane * 20;
+                        const int k0 = 16 * ch, kn = min(16, d - k0);
+                        for (int kk = 0; kk < kn; kk += 4) {
+                            const float4 qv = *reinterpret_cast<const float4*>(qrow[wave] + k0 + kk);
+                            const float4 cv = *reinterpret_cast<const float4*>(mine + kk);
+                            ip = __fmaf_rn(qv.x, cv.x, ip);
+                            ip = __fmaf_rn(qv.y, cv.y, ip);
+                            ip = __fmaf_rn(qv.z, cv.z, ip);
+                            ip = __fmaf_rn(qv.w, cv.w, ip);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            const float x = __fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip));
+            // columns do not arrive in increasing order: equal distances are queued, the key decides
+            sel.template offer<false>(x, col, valid);
+        }
+        if (kept_total && lane == 0) atomicAdd(kept_total, (unsigned long long)total);
+    } else {
+        // the whole row exactly, one column per lane, ascending columns (the ordered rule is exact)
+        for (int j0 = 0; j0 < nlist; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < nlist;
+            const int jc = valid ? j : 0;
+            const float x = exact_distance(qrow[wave], Cn + (size_t)jc * d, d, qnv, cn[jc]);
+            sel.offer(x, (uint32_t)j, valid);
+        }
+        if (kept_total && lane == 0) atomicAdd(kept_total, (unsigned long long)nlist);
+    }
+    sel.flush();
+    if (lane < nprobe) {
+        const u64 key = sel.best[0];
+        const bool miss = key == kMaxKey;
+        cdis[q * nprobe + lane] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+        keys[q * nprobe + lane] = miss ? -1 : (int64_t)(uint32_t)key;
+    }
+}
+
+}  // namespace
+
+bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 8192 && nprobe >= 2 && nprobe <= 64;
+}
+
+void launch_screen_to_half(const float* x, int64_t n, int d, float scale, void* out_half, unsigned char* flags, hipStream_t s) {
+    if (n <= 0) return;
+    const int64_t n_pad = (n + 127) / 128 * 128;
+    const int ks_n = (d + 15) / 16;
+    if (flags) (void)hipMemsetAsync(flags, 0, (size_t)n, s);
+    const int64_t tot = n_pad * 2 * ks_n;
+    hipLaunchKernelGGL(screen_to_half_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, n, n_pad, d, ks_n, scale,
+                       reinterpret_cast<_Float16*>(out_half), flags);
+}
+
+void launch_screen_row_prep(const float* x, int64_t n, int d, float scale, float* norms, unsigned char* flags, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(screen_row_prep_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, x, n, d, scale, norms, flags);
+}
+
+size_t coarse_screen_keep_bytes(int64_t nq) { return (size_t)nq * (kKeepCap + 1) * sizeof(uint16_t); }
+
+void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
+                            const float* qn, const float* cn, float* approx /* [roundup128(nq)][nlist] */, void* keep_ws, int64_t nq,
+                            int nlist, int d, int nprobe, float scale, float cmax, float* cdis, int64_t* keys,
+                            unsigned long long* kept_total, unsigned int* exact_rows, hipStream_t s) {
+    if (nq <= 0) return;
+    const int ks = (d + 15) / 16;
+    const float inv_s2 = 1.f / (scale * scale);                // a power of two
+    // the matrix holds half(sd * approximate distance), sd the power of two that puts 4 C^2 -- every distance of a query no
+    // longer than the longest centroid -- just inside the half range
+    int e = 0;
+    (void)frexpf(65504.f / (4.04f * cmax * cmax), &e);
+    const float sd = ldexpf(1.f, std::max(-120, std::min(120, e - 1)));
+    _Float16* ah = reinterpret_cast<_Float16*>(approx);
+    const _Float16* qh = reinterpret_cast<const _Float16*>(q_half);
+    const _Float16* ch = reinterpret_cast<const _Float16*>(c_half);
+    dim3 grid((unsigned)((nq + 127) / 128), (unsigned)((nlist + 127) / 128));
+#define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn, cn, ah, nq, nlist, inv_s2, sd)
+    switch (ks) {
+        case 1: VLQ_F16G(1); break;
+        case 2: VLQ_F16G(2); break;
+        case 3: VLQ_F16G(3); break;
+        case 4: VLQ_F16G(4); break;
+        case 5: VLQ_F16G(5); break;
+        case 6: VLQ_F16G(6); break;
+        case 7: VLQ_F16G(7); break;
+        default: VLQ_F16G(8); break;
+    }
+#undef VLQ_F16G
+    const float c_sub = 5.9604645e-08f /* 2^-24 */ * sqrtf((float)d) / scale * 1.001f;
+    uint16_t* keep = reinterpret_cast<uint16_t*>(keep_ws);
+    uint16_t* nkeep = keep + (size_t)nq * kKeepCap;
+    dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
+#define VLQ_SCR(NV) hipLaunchKernelGGL(coarse_screen_keep_kernel<NV>, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn, q_flags, cmax, \
+                                       c_sub, 1.f / sd, keep, nkeep, exact_rows)
+    if (nlist <= 1024) VLQ_SCR(4);
+    else if (nlist <= 2048) VLQ_SCR(8);
+    else if (nlist <= 4096) VLQ_SCR(16);
+    else VLQ_SCR(32);
+#undef VLQ_SCR
+    hipLaunchKernelGGL(coarse_screen_exact_kernel, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
+                       kept_total);
+}
+
+}  // namespace vlq

@@ -89,6 +89,16 @@ class GpuIVFPQ:
         """GpuIndexIVFPQConfig::useFloat16LookupTables for the plain IVFPQ search (include/vlq_ivfpq.h)"""
         check(lib().vlq_ivfpq_set_float16_tables(self._h, C.c_int(int(enable))))
 
+    def set_coarse_screen(self, mode):
+        """0 off, 1 on (default): float16 screen in front of the exact coarse distances (speed only; include/vlq_ivfpq.h)"""
+        check(lib().vlq_ivfpq_set_coarse_screen(self._h, C.c_int(int(mode))))
+
+    def coarse_screen_state(self):
+        """(enabled, rows screened so far, rows the screen handed to the exact path)"""
+        en, rows, und = C.c_int(0), C.c_uint64(0), C.c_uint32(0)
+        check(lib().vlq_ivfpq_coarse_screen_state(self._h, C.byref(en), C.byref(rows), C.byref(und)))
+        return bool(en.value), int(rows.value), int(und.value)
+
     def set_scan_schedule(self, mode):
         """0 automatic, 1 query-major, 2 list-owned (speed only; include/vlq_ivfpq.h)"""
         check(lib().vlq_ivfpq_set_scan_schedule(self._h, C.c_int(int(mode))))
