@@ -14,7 +14,7 @@ SYMBOLS = [
     "vlq_version", "vlq_last_error", "vlq_device_count", "vlq_ivfpq_create", "vlq_ivfpq_destroy",
     "vlq_ivfpq_set_stream", "vlq_ivfpq_set_coarse_centroids", "vlq_ivfpq_set_imi_centroids",
     "vlq_ivfpq_set_pq_centroids",
-    "vlq_ivfpq_set_search_options", "vlq_ivfpq_set_float16_tables", "vlq_ivfpq_set_scan_schedule", "vlq_ivfpq_set_lists", "vlq_ivfpq_add", "vlq_ivfpq_reserve_memory", "vlq_ivfpq_reclaim_memory", "vlq_ivfpq_encode", "vlq_ivfpq_encode_preassigned",
+    "vlq_ivfpq_set_search_options", "vlq_ivfpq_set_float16_tables", "vlq_ivfpq_set_scan_schedule", "vlq_ivfpq_set_coarse_screen", "vlq_ivfpq_coarse_screen_state", "vlq_ivfpq_set_lists", "vlq_ivfpq_add", "vlq_ivfpq_reserve_memory", "vlq_ivfpq_reclaim_memory", "vlq_ivfpq_encode", "vlq_ivfpq_encode_preassigned",
     "vlq_ivfpq_ntotal", "vlq_ivfpq_list_length", "vlq_ivfpq_get_list", "vlq_ivfpq_search",
     "vlq_ivfpq_search_preassigned", "vlq_ivfpq_coarse_search", "vlq_ivfpq_query_tables",
     "vlq_ivfpq_get_precomputed_table", "vlq_ivfpq_stats", "vlq_ivfpq_profile",
