@@ -49,18 +49,33 @@ def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
     assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
 
 
-def test_data_that_defeat_the_bound_are_done_exactly_and_drop_the_screen():
-    """Centroids 1000 + noise: |q| |c| is 10^7 times the spread of the distances, the bound keeps every column."""
+def test_offset_data_are_centred():
+    """Centroids 5 + uniform(0, 1): the norms are 25 times those of the centred data -- the half arithmetic works on q - mu,
+    c - mu (mu = the centroids' mean), only the exact stage's own rounding term keeps the uncentred norms."""
     rng = np.random.default_rng(5)
     nlist, d, nprobe = 512, 32, 16
-    g, ox, cent = make(nlist, d, rng, offset=1000.0, spread=0.01)
-    xq = (1000.0 + 0.01 * rng.random((NQ, d))).astype(np.float32)
+    g, ox, cent = make(nlist, d, rng, offset=5.0, spread=1.0)
+    xq = (5.0 + rng.random((NQ, d))).astype(np.float32)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    cd, keys = g.coarse_search(xq, nprobe)
+    assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)
+    en, rows, und = g.coarse_screen_state()
+    assert en and rows == NQ and und * 200 <= NQ
+
+
+def test_data_that_defeat_the_bound_are_done_exactly_and_drop_the_screen():
+    """8192 uniform centroids in 8 dimensions, nprobe 64: hundreds of centroids lie within the bound of the 64th nearest,
+    more than a row's list holds -- every such row is done exactly in full, and the index drops the screen by itself."""
+    rng = np.random.default_rng(7)
+    nlist, d, nprobe = 8192, 8, 64
+    g, ox, cent = make(nlist, d, rng)
+    xq = rng.random((NQ, d)).astype(np.float32)
     cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
     for it in range(3):
         cd, keys = g.coarse_search(xq, nprobe)
         assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso), it
     en, rows, und = g.coarse_screen_state()
-    assert not en and und > 0 and rows <= 2 * NQ              # dropped after the first batch's counters reached the host
+    assert not en and und * 200 > NQ and rows <= 2 * NQ       # dropped once the first batch's counters reached the host
 
 
 def test_queries_outside_the_half_range_and_nan_rows():

@@ -200,11 +200,13 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
             HIP_TRY(hipMemsetAsync(h->ws_kept.p, 0, 16, h->stream));
         }
         TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
-        vlq::launch_screen_row_prep(x_dev, n, h->d, h->screen_scale, h->ws_qn.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
-        vlq::launch_screen_to_half(x_dev, n, h->d, h->screen_scale, h->ws_xh.p, nullptr, h->stream);
+        TRY(h->ws_qn_c.reserve((size_t)n * sizeof(float)));
+        vlq::launch_screen_prep(x_dev, h->coarse_mu.as<float>(), n, h->d, h->screen_scale, h->ws_xh.p, h->ws_qn.as<float>(),
+                                h->ws_qn_c.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
         vlq::launch_coarse_screened(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->coarse_h.p,
-                                    h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_dist.as<float>(), h->ws_cand.p, n, h->nlist, h->d, nprobe,
-                                    h->screen_scale, h->screen_cmax, cdis_dev, keys_dev,
+                                    h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_qn_c.as<float>(), h->cnorm_c.as<float>(),
+                                    h->ws_dist.as<float>(), h->ws_cand.p, n, h->nlist, h->d, nprobe,
+                                    h->screen_scale, h->screen_cmax, h->screen_cmax0, cdis_dev, keys_dev,
                                     h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
                                     h->stream);
         h->screen_rows_seen += (uint64_t)n;
@@ -698,19 +700,31 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     if (h->nlist <= (1 << 17)) {      // O(nlist * d * log nlist) host work; larger indexes keep the list-id order
         std::vector<float> hc((size_t)h->nlist * h->d);
         HIP_TRY(hipMemcpy(hc.data(), h->coarse.p, bytes, hipMemcpyDeviceToHost));
-        // float16 screen of the coarse stage: power-of-two scale from the largest |component|, largest norm (rounded up)
+        // float16 screen of the coarse stage (coarse_screen.hip): the centroids' mean, power-of-two scale from the largest
+        // centred |component|, largest centred norm (rounded up)
         {
-            double amax = 0.0, nmax = 0.0;
+            std::vector<double> mud((size_t)h->d, 0.0);
             bool finite = true;
-            for (int i = 0; i < h->nlist; i++) {
-                double nn = 0.0;
+            for (int i = 0; i < h->nlist; i++)
                 for (int c = 0; c < h->d; c++) {
                     const double v = hc[(size_t)i * h->d + c];
                     finite = finite && std::isfinite(v);
+                    mud[(size_t)c] += v;
+                }
+            std::vector<float> mu((size_t)h->d);
+            for (int c = 0; c < h->d; c++) mu[(size_t)c] = finite ? (float)(mud[(size_t)c] / h->nlist) : 0.f;
+            double amax = 0.0, nmax = 0.0, nmax0 = 0.0;
+            for (int i = 0; i < h->nlist && finite; i++) {
+                double nn = 0.0, n0 = 0.0;
+                for (int c = 0; c < h->d; c++) {
+                    const double v0 = hc[(size_t)i * h->d + c];
+                    const double v = (double)(float)(hc[(size_t)i * h->d + c] - mu[(size_t)c]);     // fl(c - mu), as the kernels form it
                     amax = std::max(amax, std::fabs(v));
                     nn += v * v;
+                    n0 += v0 * v0;
                 }
                 nmax = std::max(nmax, nn);
+                nmax0 = std::max(nmax0, n0);
             }
             h->screen_ok = false;
             if (finite && amax > 0.0 && amax < 1e30 && h->d <= 128) {
@@ -718,9 +732,15 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
                 (void)std::frexp(16384.0 / amax, &e);            // 16384 / amax = m * 2^e, m in [0.5, 1)
                 h->screen_scale = std::ldexp(1.f, std::max(-100, std::min(100, e - 1)));     // s * amax <= 16384
                 h->screen_cmax = (float)(std::sqrt(nmax) * 1.0001);
+                h->screen_cmax0 = (float)(std::sqrt(nmax0) * 1.0001);
                 const int dp = (h->d + 15) / 16 * 16;
+                TRY(h->coarse_mu.reserve((size_t)h->d * sizeof(float)));
+                HIP_TRY(hipMemcpy(h->coarse_mu.p, mu.data(), (size_t)h->d * sizeof(float), hipMemcpyHostToDevice));
                 TRY(h->coarse_h.reserve((size_t)((h->nlist + 127) / 128 * 128) * dp * 2));
-                vlq::launch_screen_to_half(h->coarse.as<float>(), h->nlist, h->d, h->screen_scale, h->coarse_h.p, nullptr, h->stream);
+                TRY(h->cnorm_c.reserve((size_t)h->nlist * sizeof(float)));
+                TRY(h->ws_misc.reserve((size_t)h->nlist * sizeof(float)));
+                vlq::launch_screen_prep(h->coarse.as<float>(), h->coarse_mu.as<float>(), h->nlist, h->d, h->screen_scale, h->coarse_h.p,
+                                        h->ws_misc.as<float>(), h->cnorm_c.as<float>(), nullptr, h->stream);
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 h->screen_ok = true;
             }

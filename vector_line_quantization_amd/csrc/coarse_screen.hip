@@ -17,12 +17,22 @@
 //     |ip~ / s^2 - <q, c>|  <=  (2^-10 + 2^-16 + 2^-20) |q| |c|  +  2^-25 sqrt(d) (|q| + |c|) / s
 // (Cauchy-Schwarz on sum |q_i c_i| and on sum |c_i|).  The exact stage's own fp32 value differs from the real-number
 // distance by at most 2^-15 (|q| + |c|)^2 (128-term fmaf chain, the two norms, three more roundings).  Hence
-//     |approximate - exact|  <=  delta(q) := 1.04 * 2^-9 |q| C + 2^-24 sqrt(d) (|q| + C) / s + 2^-14 (|q| + C)^2,
+//     |approximate - exact|  <=  delta(q) := 1.04 * 2^-9 |q| C + 2^-24 sqrt(d) (|q| + C) / s + 2^-15 (|q| + C)^2,
 // C = the largest centroid norm.  Let cut >= the nprobe-th smallest approximate distance of the row.  nprobe columns
 // have exact distance <= cut + delta, so the nprobe-th smallest EXACT distance is <= cut + delta, and a column whose
 // approximate distance exceeds cut + 2 delta has exact distance > cut + delta: it cannot be among the nprobe nearest,
-// nor tie with the nprobe-th.  Rows where that test keeps fewer than nprobe or more than 512 columns (NaN / infinite
+// nor tie with the nprobe-th.  Rows where that test keeps fewer than nprobe or more than 256 columns (NaN / infinite
 // input, degenerate data) are recomputed in full by the same fmaf chains.
+//
+// Centring.  |q - c| = |(q - mu) - (c - mu)| for every mu, and the bound is proportional to |q| |c|: the half copies, the
+// norms of the approximate matrix and delta are those of q - mu and c - mu, mu = the centroids' mean (descriptor data are
+// non-negative: their mean carries most of the norm).  fl(q_i - mu_i) is the real difference within 2^-24 relative --
+// absorbed by the 1.04 above -- and the approximate norms |q - mu|^2, |c - mu|^2 within 2^-17, inside a 2^-15 (|q - mu| + C')^2
+// term of their own.  The EXACT distances are computed from the original q, c and their norms, untouched by any of this --
+// which is why the 2^-15 (|q| + C)^2 of the exact stage's own rounding keeps the UNcentred norms: data far from the origin
+// have exact fp32 distances that are noise at the scale of their differences, and reproducing that noise needs every column.
+// The stored matrix is half(sd * approximate distance) (the 164 MB fp32 matrix was what both kernels were bound by): its
+// rounding, 2^-11 of the stored value, enters the keep test as a relative widening of both sides (coarse_screen_keep_kernel).
 #include <algorithm>
 #include <cmath>
 
@@ -37,30 +47,6 @@ namespace {
 #define FLT_MAX_F 3.402823466e+38f
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// x [n][d] -> half(scale * x) in the MFMA's operand order: rows in blocks of 32, components in steps of 16; block
-// (row / 32, ks) is 1 KB = lane (r = row % 32, h = (k % 16) / 8) x 8 halves, so a wave's operand load of one block is
-// one contiguous KB.  Rows n .. n_pad - 1 are zero.  One thread per (row, 8 components): 32-byte reads, 16-byte writes.
-// flags[row] = 1 where a component leaves the half range or is not a number (flags != nullptr: zeroed by the launcher).
-__global__ void screen_to_half_kernel(const float* __restrict__ x, int64_t n, int64_t n_pad, int d, int ks_n, float scale,
-                                      _Float16* __restrict__ out, unsigned char* __restrict__ flags) {
-    const int gpr = 2 * ks_n;                                  // 8-component groups per row
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_pad * gpr) return;
-    const int64_t row = e / gpr;
-    const int grp = (int)(e % gpr), ks = grp >> 1, h = grp & 1;
-    h16x8 v;
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int k = 8 * grp + i;
-        const float f = (row < n && k < d) ? __fmul_rn(scale, x[row * d + k]) : 0.f;
-        bad = bad || !(fabsf(f) <= 65504.f);                   // also true for NaN
-        v[i] = (_Float16)f;
-    }
-    *reinterpret_cast<h16x8*>(out + (((row >> 5) * ks_n + ks) * 64 + h * 32 + (row & 31)) * 8) = v;
-    if (bad && flags) flags[row] = 1;                          // (same value from every writer)
-}
 
 // approximate distances: out[row][col] = (qn[row] + cn[col]) - 2 * <q~, c~> / s^2.  A wave owns a 64 x 64 tile and
 // takes its operands straight from global memory in the MFMA's own layout (lane (r, h): row / column r of a 32-block,
@@ -172,20 +158,48 @@ __device__ __forceinline__ float exact_distance(const float* qrow, const float* 
     return __fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip));
 }
 
-// squared norms in fvec_norm_L2sqr's order (norm_sse_order: what the matrix path uses) and the half-range flag of a
-// row, one thread per row (the norm's additions are sequential)
-__global__ void screen_row_prep_kernel(const float* __restrict__ x, int64_t n, int d, float scale, float* __restrict__ norms,
-                                       unsigned char* __restrict__ flags) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
-    const float* xr = x + row * d;
+// Everything the screen needs of a batch of rows x [n][d], one pass: a workgroup stages 64 rows in LDS with coalesced
+// loads (rows padded to d + 1 floats), then
+//   * all threads write half(scale * (x - mu)) in the MFMA's operand order: rows in blocks of 32, components in steps of
+//     16; block (row / 32, ks) is 1 KB = lane (r = row % 32, h = (k % 16) / 8) x 8 halves, so a wave's operand load of one
+//     block is one contiguous KB.  Rows n .. n_pad - 1 (n_pad = n rounded up to 128) and components d .. 16 ks_n - 1 are zero;
+//   * one thread per row walks its row -- the reference's additions are sequential -- for the squared norm in
+//     fvec_norm_L2sqr's order (norm_sse_order: what the matrix path uses; the exact distances need it), the squared norm of
+//     the centred row (the approximate matrix and delta need it; any order) and the half-range flag of the centred, scaled
+//     row (flags optional).
+__global__ __launch_bounds__(256) void screen_prep_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d,
+                                                          int ks_n, float scale, _Float16* __restrict__ out, float* __restrict__ norms,
+                                                          float* __restrict__ norms_c, unsigned char* __restrict__ flags) {
+    extern __shared__ float rows[];                            // [64][d + 1]
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int nr = (int)max((int64_t)0, min((int64_t)64, n - row0));
+    const int t = threadIdx.x;
+    for (int e = t; e < nr * d; e += 256) rows[(e / d) * (d + 1) + e % d] = x[row0 * d + e];
+    __syncthreads();
+    const int gpr = 2 * ks_n;                                  // 8-component groups per row
+    for (int e = t; e < 64 * gpr; e += 256) {
+        const int r = e / gpr, grp = e % gpr, ks = grp >> 1, h = grp & 1;
+        h16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = 8 * grp + i;
+            v[i] = (_Float16)((r < nr && k < d) ? __fmul_rn(scale, __fsub_rn(rows[r * (d + 1) + k], mu[k])) : 0.f);
+        }
+        const int64_t row = row0 + r;
+        *reinterpret_cast<h16x8*>(out + (((row >> 5) * ks_n + ks) * 64 + h * 32 + (row & 31)) * 8) = v;
+    }
+    if (t >= nr) return;
+    const float* xr = rows + t * (d + 1);
     bool bad = false;
-    norms[row] = norm_sse_order([&](int c) {
-        const float v = xr[c];
-        bad = bad || !(fabsf(__fmul_rn(scale, v)) <= 65504.f);      // also true for NaN
-        return v;
-    }, d);
-    flags[row] = bad ? 1 : 0;
+    float nc = 0.f;
+    for (int c = 0; c < d; c++) {
+        const float w = __fsub_rn(xr[c], mu[c]);
+        nc = __fmaf_rn(w, w, nc);
+        bad = bad || !(fabsf(__fmul_rn(scale, w)) <= 65504.f);      // also true for NaN
+    }
+    norms[row0 + t] = norm_sse_order([&](int c) { return xr[c]; }, d);
+    norms_c[row0 + t] = nc;
+    if (flags) flags[row0 + t] = bad ? 1 : 0;
 }
 
 constexpr int kKeepCap = 256;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
@@ -194,8 +208,9 @@ constexpr int kKeepCap = 256;                   // kept columns per row (typical
 // columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
 template <int NV>
 __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
-                                                                 const float* __restrict__ qn, const unsigned char* __restrict__ flags,
-                                                                 float cmax, float c_sub, float inv_sd, uint16_t* __restrict__ keep,
+                                                                 const float* __restrict__ qn, const float* __restrict__ qn0,
+                                                                 const unsigned char* __restrict__ flags, float cmax, float cmax0,
+                                                                 float c_sub, float inv_sd, uint16_t* __restrict__ keep,
                                                                  uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -219,11 +234,14 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
     const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
     const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));      // scaled by sd, rounded to half
     // delta(q), inflated: every factor rounded up generously (the bound is what exactness rests on)
+    // (qn / cmax: centred -- the half arithmetic's error; qn0 / cmax0: as given -- the exact stage's own fp32 error)
     const float qnorm = __fmul_rn(sqrtf(fmaxf(qnv, 0.f)), 1.0001f);
     const float sum = __fadd_rn(qnorm, cmax);
+    const float sum0 = __fadd_rn(__fmul_rn(sqrtf(fmaxf(qn0[q], 0.f)), 1.0001f), cmax0);
     const float delta = __fmul_rn(1.001f, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(0.00203125f /* 1.04 * 2^-9 */, qnorm), cmax),
                                                               __fmul_rn(c_sub, sum)),
-                                                    __fmul_rn(6.103515625e-05f /* 2^-14 */, __fmul_rn(sum, sum))));
+                                                    __fadd_rn(__fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum, sum)),
+                                                              __fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum0, sum0)))));
     // a stored value w stands for an approximate distance within 2^-11 |w| / sd (+ the subnormal step) of x = w / sd: a column
     // is kept iff the smallest distance its stored value allows is <= the largest the cut's allows + 2 delta, i.e. iff
     // x - eps |x| - sub <= thr.  For thr + sub >= 0 that is x <= (thr + sub) / (1 - eps) (every negative x passes), otherwise
@@ -378,26 +396,20 @@ bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
     return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 8192 && nprobe >= 2 && nprobe <= 64;
 }
 
-void launch_screen_to_half(const float* x, int64_t n, int d, float scale, void* out_half, unsigned char* flags, hipStream_t s) {
+void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
+                        unsigned char* flags, hipStream_t s) {
     if (n <= 0) return;
     const int64_t n_pad = (n + 127) / 128 * 128;
-    const int ks_n = (d + 15) / 16;
-    if (flags) (void)hipMemsetAsync(flags, 0, (size_t)n, s);
-    const int64_t tot = n_pad * 2 * ks_n;
-    hipLaunchKernelGGL(screen_to_half_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, n, n_pad, d, ks_n, scale,
-                       reinterpret_cast<_Float16*>(out_half), flags);
-}
-
-void launch_screen_row_prep(const float* x, int64_t n, int d, float scale, float* norms, unsigned char* flags, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(screen_row_prep_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, x, n, d, scale, norms, flags);
+    hipLaunchKernelGGL(screen_prep_kernel, dim3((unsigned)(n_pad / 64)), dim3(256), (size_t)64 * (d + 1) * sizeof(float), s, x, mu, n, d,
+                       (d + 15) / 16, scale, reinterpret_cast<_Float16*>(out_half), norms, norms_c, flags);
 }
 
 size_t coarse_screen_keep_bytes(int64_t nq) { return (size_t)nq * (kKeepCap + 1) * sizeof(uint16_t); }
 
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
-                            const float* qn, const float* cn, float* approx /* [roundup128(nq)][nlist] */, void* keep_ws, int64_t nq,
-                            int nlist, int d, int nprobe, float scale, float cmax, float* cdis, int64_t* keys,
+                            const float* qn, const float* cn, const float* qn_c, const float* cn_c,
+                            float* approx /* [roundup128(nq)][nlist] halves */, void* keep_ws, int64_t nq,
+                            int nlist, int d, int nprobe, float scale, float cmax, float cmax0, float* cdis, int64_t* keys,
                             unsigned long long* kept_total, unsigned int* exact_rows, hipStream_t s) {
     if (nq <= 0) return;
     const int ks = (d + 15) / 16;
@@ -411,7 +423,7 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     const _Float16* qh = reinterpret_cast<const _Float16*>(q_half);
     const _Float16* ch = reinterpret_cast<const _Float16*>(c_half);
     dim3 grid((unsigned)((nq + 127) / 128), (unsigned)((nlist + 127) / 128));
-#define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn, cn, ah, nq, nlist, inv_s2, sd)
+#define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn_c, cn_c, ah, nq, nlist, inv_s2, sd)
     switch (ks) {
         case 1: VLQ_F16G(1); break;
         case 2: VLQ_F16G(2); break;
@@ -427,8 +439,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     uint16_t* keep = reinterpret_cast<uint16_t*>(keep_ws);
     uint16_t* nkeep = keep + (size_t)nq * kKeepCap;
     dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
-#define VLQ_SCR(NV) hipLaunchKernelGGL(coarse_screen_keep_kernel<NV>, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn, q_flags, cmax, \
-                                       c_sub, 1.f / sd, keep, nkeep, exact_rows)
+#define VLQ_SCR(NV) hipLaunchKernelGGL(coarse_screen_keep_kernel<NV>, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, \
+                                       cmax0, c_sub, 1.f / sd, keep, nkeep, exact_rows)
     if (nlist <= 1024) VLQ_SCR(4);
     else if (nlist <= 2048) VLQ_SCR(8);
     else if (nlist <= 4096) VLQ_SCR(16);

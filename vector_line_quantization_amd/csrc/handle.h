@@ -112,7 +112,7 @@ struct vlq_ivfpq_s {
     int coarse_s_stride = 0;
     // float16 screen of the coarse stage (coarse_screen.hip): half(scale * centroids) [nlist][roundup16(d)], the power-of-two
     // scale, the largest centroid norm; 0 = off, 1 = on (default where the shape allows)
-    DevBuf coarse_h, ws_xh, ws_xflags, ws_kept, ws_screen_cnt;
+    DevBuf coarse_h, coarse_mu, cnorm_c, ws_qn_c, ws_xh, ws_xflags, ws_kept, ws_screen_cnt;     // mu = the centroids' mean; *_c: centred
     // rows the screen could not decide (too many / too few columns kept -> done exactly, slowly): counted on the device, mirrored
     // into page-locked memory by an asynchronous copy after every batch and looked at before the next -- an index whose data
     // defeat the bound (0.5 % of the rows) goes back to the matrix path for good
@@ -120,7 +120,7 @@ struct vlq_ivfpq_s {
     uint64_t screen_rows_seen = 0, screen_rows_copied = 0;
     bool screen_ok = false;
     int coarse_screen = 1;
-    float screen_scale = 1.f, screen_cmax = 0.f;
+    float screen_scale = 1.f, screen_cmax = 0.f, screen_cmax0 = 0.f;       // max |c - mu|, max |c|
     int coarse_filter = 0;        // 1 (VLQ_COARSE_FILTER=1): the filtered coarse stage -- exact, measured SLOWER than the
                                   // matrix path (0.218 against 0.159 ms at C1), kept for A/B only
     // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,

@@ -35,14 +35,18 @@ void launch_coarse_argmin(const void* tile_keys, int64_t nq, int nlist, float* c
 // exact fp32 distances (the f32 MFMA kernel's fmaf chain) for the kept columns only -- the keys, distances and tie order
 // of the matrix path.  approx: [roundup128(nq)][nlist] floats of scratch; kept_total (optional): += kept columns.
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe);
-// half copy in the MFMA operand order, [roundup128(n)] rows x roundup16(d) halves; flags [n] optional
-void launch_screen_to_half(const float* x, int64_t n, int d, float scale, void* out_half, unsigned char* flags, hipStream_t s);
-void launch_screen_row_prep(const float* x, int64_t n, int d, float scale, float* norms, unsigned char* flags, hipStream_t s);
+// one pass over x [n][d]: half(scale * (x - mu)) in the MFMA operand order ([roundup128(n)] rows x roundup16(d) halves), per row
+// |x|^2 (reference order), |x - mu|^2 and the half-range flag of scale * (x - mu) (flags optional)
+void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
+                        unsigned char* flags, hipStream_t s);
 size_t coarse_screen_keep_bytes(int64_t nq);      // keep_ws of launch_coarse_screened
+// qn / cn: exact squared norms (reference order) of queries / centroids; qn_c / cn_c: of the centred ones; cmax = max |c - mu|
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
-                            const float* qn, const float* cn, float* approx, void* keep_ws, int64_t nq, int nlist, int d, int nprobe,
-                            float scale, float cmax, float* cdis, int64_t* keys, unsigned long long* kept_total,
-                            unsigned int* exact_rows /* += rows the screen could not decide (optional) */, hipStream_t s);
+                            const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* approx, void* keep_ws,
+                            int64_t nq, int nlist, int d, int nprobe, float scale, float cmax, float cmax0 /* max |c| */, float* cdis,
+                            int64_t* keys,
+                            unsigned long long* kept_total, unsigned int* exact_rows /* += rows the screen could not decide (optional) */,
+                            hipStream_t s);
 
 // filtered coarse stage (no distance matrix; kernels.hip): a sample of the column tiles (stride s) gives every
 // row an exact upper bound of its nprobe-th smallest distance, the full pass keeps only the elements at or
