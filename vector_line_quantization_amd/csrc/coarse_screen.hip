@@ -204,6 +204,34 @@ __global__ __launch_bounds__(256) void screen_prep_kernel(const float* __restric
 
 constexpr int kKeepCap = 256;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
 
+// T: the largest stored value (half(sd * approximate distance), read back as float) a column of this row may have and still
+// be kept, from the row's cut (nprobe-th smallest stored lane minimum); *finite = the bound is a number
+__device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float qn0v, float cmax, float cmax0, float c_sub, float inv_sd,
+                                                  bool* finite) {
+    // delta(q), inflated: every factor rounded up generously (the bound is what exactness rests on)
+    // (qn / cmax: centred -- the half arithmetic's error; qn0 / cmax0: as given -- the exact stage's own fp32 error)
+    const float qnorm = __fmul_rn(sqrtf(fmaxf(qnv, 0.f)), 1.0001f);
+    const float sum = __fadd_rn(qnorm, cmax);
+    const float sum0 = __fadd_rn(__fmul_rn(sqrtf(fmaxf(qn0v, 0.f)), 1.0001f), cmax0);
+    const float delta = __fmul_rn(1.001f, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(0.00203125f /* 1.04 * 2^-9 */, qnorm), cmax),
+                                                              __fmul_rn(c_sub, sum)),
+                                                    __fadd_rn(__fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum, sum)),
+                                                              __fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum0, sum0)))));
+    // a stored value w stands for an approximate distance within 2^-11 |w| / sd (+ the subnormal step) of x = w / sd: a column
+    // is kept iff the smallest distance its stored value allows is <= the largest the cut's allows + 2 delta, i.e. iff
+    // x - eps |x| - sub <= thr.  For thr + sub >= 0 that is x <= (thr + sub) / (1 - eps) (every negative x passes), otherwise
+    // x <= (thr + sub) / (1 + eps): ONE compare per element against T (rounded up), in the stored domain.
+    const float cut = __fmul_rn(inv_sd, cut_s);
+    const float sub = __fmul_rn(inv_sd, 6.0e-8f /* > 2^-24, the subnormal half step */);
+    const float thr = __fadd_rn(__fadd_rn(__fadd_rn(cut, __fmul_rn(0.000489f /* > 2^-11 */, fabsf(cut))), sub), __fmul_rn(2.0002f, delta));
+    const float ts = __fadd_rn(thr, sub);
+    const float tx = ts >= 0.f ? __fmul_rn(ts, 1.00049f /* > 1 / (1 - eps) */) : __fmul_rn(ts, 0.99951f /* < 1 / (1 + eps): towards 0 */);
+    // back to the stored domain, rounded up (1 / inv_sd is the power of two sd: exact)
+    const float T = __fmul_rn(__fadd_rn(tx, __fmul_rn(1e-6f, fabsf(tx))), 1.f / inv_sd);
+    *finite = thr < FLT_MAX_F && T < FLT_MAX_F;
+    return T;
+}
+
 // one wave per row: the row of approximate distances in registers, cut = nprobe-th smallest of the 64 lane minima,
 // columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
 template <int NV>
@@ -233,27 +261,9 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
     }
     const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
     const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));      // scaled by sd, rounded to half
-    // delta(q), inflated: every factor rounded up generously (the bound is what exactness rests on)
-    // (qn / cmax: centred -- the half arithmetic's error; qn0 / cmax0: as given -- the exact stage's own fp32 error)
-    const float qnorm = __fmul_rn(sqrtf(fmaxf(qnv, 0.f)), 1.0001f);
-    const float sum = __fadd_rn(qnorm, cmax);
-    const float sum0 = __fadd_rn(__fmul_rn(sqrtf(fmaxf(qn0[q], 0.f)), 1.0001f), cmax0);
-    const float delta = __fmul_rn(1.001f, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(0.00203125f /* 1.04 * 2^-9 */, qnorm), cmax),
-                                                              __fmul_rn(c_sub, sum)),
-                                                    __fadd_rn(__fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum, sum)),
-                                                              __fmul_rn(3.0517578125e-05f /* 2^-15 */, __fmul_rn(sum0, sum0)))));
-    // a stored value w stands for an approximate distance within 2^-11 |w| / sd (+ the subnormal step) of x = w / sd: a column
-    // is kept iff the smallest distance its stored value allows is <= the largest the cut's allows + 2 delta, i.e. iff
-    // x - eps |x| - sub <= thr.  For thr + sub >= 0 that is x <= (thr + sub) / (1 - eps) (every negative x passes), otherwise
-    // x <= (thr + sub) / (1 + eps): ONE compare per element against T (rounded up), in the stored domain.
-    const float cut = __fmul_rn(inv_sd, cut_s);
-    const float sub = __fmul_rn(inv_sd, 6.0e-8f /* > 2^-24, the subnormal half step */);
-    const float thr = __fadd_rn(__fadd_rn(__fadd_rn(cut, __fmul_rn(0.000489f /* > 2^-11 */, fabsf(cut))), sub), __fmul_rn(2.0002f, delta));
-    const float ts = __fadd_rn(thr, sub);
-    const float tx = ts >= 0.f ? __fmul_rn(ts, 1.00049f /* > 1 / (1 - eps) */) : __fmul_rn(ts, 0.99951f /* < 1 / (1 + eps): towards 0 */);
-    // back to the stored domain, rounded up (1 / inv_sd is the power of two sd: exact)
-    const float T = __fmul_rn(__fadd_rn(tx, __fmul_rn(1e-6f, fabsf(tx))), 1.f / inv_sd);
-    const bool undecided = !(thr < FLT_MAX_F) || !(T < FLT_MAX_F) || flags[q];       // NaN / infinite bound, or a query outside the half range
+    bool finite;
+    const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
+    const bool undecided = !finite || flags[q];       // NaN / infinite bound, or a query outside the half range
     // kept columns: a ballot per register component (most are empty: ~nprobe + 20 of the row's elements pass)
     uint16_t* out = keep + q * kKeepCap;
     int total = 0;
@@ -273,6 +283,67 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
         take(v[u].y, c0 + 1);
         take(v[u].z, c0 + 2);
         take(v[u].w, c0 + 3);
+    }
+    const bool exact_row = undecided || total > kKeepCap || total < nprobe;
+    if (lane == 0) {
+        nkeep[q] = exact_row ? (uint16_t)0xffff : (uint16_t)total;
+        if (exact_row && exact_rows) atomicAdd(exact_rows, 1u);
+    }
+}
+
+// the same for rows wider than 8192 columns (up to 65 536: the multi-index halves, the many-list indexes): two passes over
+// the row, 4096 columns at a time -- lane minima and the cut, then the compare + ballot (the second pass reads L2)
+__global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
+                                                                        const float* __restrict__ qn, const float* __restrict__ qn0,
+                                                                        const unsigned char* __restrict__ flags, float cmax, float cmax0,
+                                                                        float c_sub, float inv_sd, uint16_t* __restrict__ keep,
+                                                                        uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
+    constexpr int NV = 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // whole wave; no workgroup barrier below
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const h16x4* row4 = reinterpret_cast<const h16x4*>(dist + q * nlist);
+    const int n4 = nlist >> 2;
+    float mn = FLT_MAX_F;
+    for (int b4 = 0; b4 < n4; b4 += NV * 64) {
+        h16x4 hv[NV];
+#pragma unroll
+        for (int u = 0; u < NV; u++) hv[u] = row4[min(b4 + u * 64 + lane, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < NV; u++)
+            if (b4 + u * 64 + lane < n4)
+                mn = fminf(mn, fminf(fminf((float)hv[u][0], (float)hv[u][1]), fminf((float)hv[u][2], (float)hv[u][3])));
+    }
+    const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
+    const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));
+    bool finite;
+    const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
+    const bool undecided = !finite || flags[q];
+    uint16_t* out = keep + q * kKeepCap;
+    int total = 0;
+    auto take = [&](float w, uint32_t col, bool in) __attribute__((always_inline)) {
+        const bool p = in && w <= T;
+        const u64 m = __ballot(p);
+        if (m != 0) {
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (p && pos < kKeepCap) out[pos] = (uint16_t)col;
+            total += __popcll(m);
+        }
+    };
+    for (int b4 = 0; b4 < n4 && total <= kKeepCap; b4 += NV * 64) {
+        h16x4 hv[NV];
+#pragma unroll
+        for (int u = 0; u < NV; u++) hv[u] = row4[min(b4 + u * 64 + lane, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const int i4 = b4 + u * 64 + lane;
+            const uint32_t c0 = (uint32_t)(4 * i4);
+            take((float)hv[u][0], c0 + 0, i4 < n4);
+            take((float)hv[u][1], c0 + 1, i4 < n4);
+            take((float)hv[u][2], c0 + 2, i4 < n4);
+            take((float)hv[u][3], c0 + 3, i4 < n4);
+        }
     }
     const bool exact_row = undecided || total > kKeepCap || total < nprobe;
     if (lane == 0) {
@@ -393,7 +464,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t
 }  // namespace
 
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
-    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 8192 && nprobe >= 2 && nprobe <= 64;
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 64;
 }
 
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
@@ -444,7 +515,10 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     if (nlist <= 1024) VLQ_SCR(4);
     else if (nlist <= 2048) VLQ_SCR(8);
     else if (nlist <= 4096) VLQ_SCR(16);
-    else VLQ_SCR(32);
+    else if (nlist <= 8192) VLQ_SCR(32);
+    else
+        hipLaunchKernelGGL(coarse_screen_keep_stream_kernel, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
+                           c_sub, 1.f / sd, keep, nkeep, exact_rows);
 #undef VLQ_SCR
     hipLaunchKernelGGL(coarse_screen_exact_kernel, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
                        kept_total);
