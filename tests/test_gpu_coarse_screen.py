@@ -27,11 +27,7 @@ def make(nlist, d, rng, offset=0.0, spread=1.0):
 
 
 @pytest.mark.parametrize("nlist,d,nprobe,decides", [(256, 16, 8, True), (1024, 64, 32, True), (2048, 100, 17, True),
-                                                    (4096, 128, 32, True), (4096, 96, 2, True),
-                                                    # uniform data, many centroids, few dimensions: the distances of a row are
-                                                    # so dense around the 64th that the bound keeps more columns than a row's
-                                                    # list holds -- those rows are done exactly in full
-                                                    (8192, 32, 64, False),
+                                                    (4096, 128, 32, True), (4096, 96, 2, True), (8192, 8, 32, True),
                                                     # rows wider than 8192 columns: the two-pass streaming keep kernel
                                                     (16384, 64, 32, None), (65536, 16, 8, None)])
 def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
@@ -67,12 +63,13 @@ def test_offset_data_are_centred():
 
 
 def test_data_that_defeat_the_bound_are_done_exactly_and_drop_the_screen():
-    """8192 uniform centroids in 8 dimensions, nprobe 64: hundreds of centroids lie within the bound of the 64th nearest,
-    more than a row's list holds -- every such row is done exactly in full, and the index drops the screen by itself."""
+    """Centroids and queries 100 + uniform(0, 1) in 16 dimensions: the exact fp32 distances -- differences of numbers near
+    320 000 -- are themselves uncertain by more than their spread, the bound (rightly) keeps every column, every row is done
+    exactly in full, and the index drops the screen by itself."""
     rng = np.random.default_rng(7)
-    nlist, d, nprobe = 8192, 8, 64
-    g, ox, cent = make(nlist, d, rng)
-    xq = rng.random((NQ, d)).astype(np.float32)
+    nlist, d, nprobe = 1024, 16, 8
+    g, ox, cent = make(nlist, d, rng, offset=100.0, spread=1.0)
+    xq = (100.0 + rng.random((NQ, d))).astype(np.float32)
     cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
     for it in range(3):
         cd, keys = g.coarse_search(xq, nprobe)
@@ -103,3 +100,39 @@ def test_queries_outside_the_half_range_and_nan_rows():
     g.set_coarse_screen(0)
     cd0, keys0 = g.coarse_search(xq, nprobe)
     assert np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(keys1, keys0)
+
+
+@pytest.mark.parametrize("nbits,d,nprobe", [(8, 128, 16), (10, 64, 32)])
+def test_multi_index_halves_go_through_the_screen(nbits, d, nprobe):
+    """Inverted multi-index: each half's table of 2^nbits sub-centroids is screened like a flat quantizer's; the walk over
+    the two sorted lists (MinSumK) sees the same T nearest sub-centroids and distances, so the cells and their sums are
+    the oracle's."""
+    rng = np.random.default_rng(nbits * 100 + nprobe)
+    kc, dc, M = 1 << nbits, d // 2, 16
+    imi = rng.random((2, kc, dc), dtype=np.float32)
+    imi[0, 7:20] = imi[0, 5]                                  # ties among sub-centroids
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.4).astype(np.float32)
+    xq = rng.random((NQ, d), dtype=np.float32)
+    ox = OracleIndex(d, kc * kc, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits)
+    g = vlq.GpuIVFPQ(d, kc * kc, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    cd, keys = g.coarse_search(xq, nprobe)
+    en, rows, und = g.coarse_screen_state()
+    assert rows == 2 * NQ                                     # both halves
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+    g.set_coarse_screen(0)
+    cd0, keys0 = g.coarse_search(xq, nprobe)
+    assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
+
+
+def test_more_than_32_probes_take_the_matrix_path():
+    rng = np.random.default_rng(9)
+    g, ox, cent = make(1024, 32, rng)
+    xq = rng.random((NQ, 32)).astype(np.float32)
+    cd, keys = g.coarse_search(xq, 48)
+    assert g.coarse_screen_state()[1] == 0                    # no row went through the screen
+    cdo, keyso = ox.coarse_search(xq, 48, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)

@@ -59,3 +59,4 @@ res = scale_checks.check_ivfpq_sample(g, xq[pick].cpu().numpy(), nprobe, k, pq, 
 print("oracle sample check:", res, flush=True)
 assert s1 >= 0.99 and res["ok"], "verification failed"
 print("VERIFIED")
+print("coarse screen (enabled, rows screened, rows done exactly in full):", g.coarse_screen_state())

@@ -182,7 +182,7 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
     // (below ~2000 rows the screen's five short kernels cost more than the matrix path's two: 1250 rows 46 against 40 us)
-    if (!direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_screen && h->screen_ok && n >= 2048 &&
+    if (!direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_screen && h->screen.ok && n >= 2048 &&
         vlq::coarse_screen_shape_ok(h->nlist, h->d, nprobe)) {
         if (!h->screen_cnt_host) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
@@ -201,12 +201,12 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
         }
         TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
         TRY(h->ws_qn_c.reserve((size_t)n * sizeof(float)));
-        vlq::launch_screen_prep(x_dev, h->coarse_mu.as<float>(), n, h->d, h->screen_scale, h->ws_xh.p, h->ws_qn.as<float>(),
+        vlq::launch_screen_prep(x_dev, h->screen.mu.as<float>(), n, h->d, h->screen.scale, h->ws_xh.p, h->ws_qn.as<float>(),
                                 h->ws_qn_c.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
-        vlq::launch_coarse_screened(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->coarse_h.p,
-                                    h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_qn_c.as<float>(), h->cnorm_c.as<float>(),
+        vlq::launch_coarse_screened(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->screen.half.p,
+                                    h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_qn_c.as<float>(), h->screen.norm_c.as<float>(),
                                     h->ws_dist.as<float>(), h->ws_cand.p, n, h->nlist, h->d, nprobe,
-                                    h->screen_scale, h->screen_cmax, h->screen_cmax0, cdis_dev, keys_dev,
+                                    h->screen.scale, h->screen.cmax, h->screen.cmax0, cdis_dev, keys_dev,
                                     h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
                                     h->stream);
         h->screen_rows_seen += (uint64_t)n;
@@ -266,10 +266,41 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     float* hv = (float*)p;
     p += b_hv;
     float* sub = (float*)p;
+    if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
+        (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
+        h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
     for (int m = 0; m < 2; m++) {
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
         float* tmin = nullptr;
         bool argmin = false;
+        if (dc >= 16 && h->coarse_screen && h->imi_screen[m].ok && n >= 2048 && vlq::coarse_screen_shape_ok(kc, dc, T)) {
+            // float16 screen of this half's table (coarse_screen.hip): approximate half matrix in tab[m], kept columns, exact
+            // fmaf chains, exact select -- the T nearest sub-centroids and their distances as the matrix path returns them
+            const vlq_ivfpq_s::ScreenSet& sc = h->imi_screen[m];
+            const int dp = (dc + 15) / 16 * 16;
+            if (!h->screen_cnt_host) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
+                *h->screen_cnt_host = 0;
+                TRY(h->ws_screen_cnt.reserve(8));
+                HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream));
+            }
+            TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
+            TRY(h->ws_xflags.reserve((size_t)n));
+            TRY(h->ws_qn.reserve((size_t)n * 4));
+            TRY(h->ws_qn_c.reserve((size_t)n * 4));
+            TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
+            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
+            vlq::launch_screen_prep(sub, sc.mu.as<float>(), n, dc, sc.scale, h->ws_xh.p, h->ws_qn.as<float>(), h->ws_qn_c.as<float>(),
+                                    h->ws_xflags.as<unsigned char>(), h->stream);
+            vlq::launch_coarse_screened(sub, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), cent, sc.half.p, h->ws_qn.as<float>(),
+                                        h->imi_norm.as<float>() + (size_t)m * kc, h->ws_qn_c.as<float>(), sc.norm_c.as<float>(), tab[m],
+                                        h->ws_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
+                                        h->ws_screen_cnt.as<unsigned int>(), h->stream);
+            h->screen_rows_seen += (uint64_t)n;
+            HIP_TRY(hipMemcpyAsync(h->screen_cnt_host, h->ws_screen_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
+            h->screen_rows_copied = h->screen_rows_seen;
+            continue;
+        }
         if (dc < 16) {
             // compute_distance_table (ProductQuantizer.cpp:410-422): fvec_L2sqr per entry
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
@@ -684,6 +715,55 @@ static void spatial_list_rank(const float* cent, int nlist, int d, std::vector<i
     for (int i = 0; i < nlist; i++) rank[(size_t)order[(size_t)i]] = i;
 }
 
+// float16 screen of a coarse stage (coarse_screen.hip) for one centroid set: the centroids' mean, power-of-two scale from the
+// largest centred |component|, largest centred / uncentred norm (rounded up), half copy and centred norms on the device.
+// hc: host copy of the n x d centroids at cent_dev.
+static int build_screen(vlq_ivfpq_t h, const float* hc, const float* cent_dev, int n, int d, vlq_ivfpq_s::ScreenSet& sc) {
+    sc.ok = false;
+    if (d > 128 || n < 1) return VLQ_OK;
+    std::vector<double> mud((size_t)d, 0.0);
+    bool finite = true;
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < d; c++) {
+            const double v = hc[(size_t)i * d + c];
+            finite = finite && std::isfinite(v);
+            mud[(size_t)c] += v;
+        }
+    if (!finite) return VLQ_OK;
+    std::vector<float> mu((size_t)d);
+    for (int c = 0; c < d; c++) mu[(size_t)c] = (float)(mud[(size_t)c] / n);
+    double amax = 0.0, nmax = 0.0, nmax0 = 0.0;
+    for (int i = 0; i < n; i++) {
+        double nn = 0.0, n0 = 0.0;
+        for (int c = 0; c < d; c++) {
+            const double v0 = hc[(size_t)i * d + c];
+            const double v = (double)(float)(hc[(size_t)i * d + c] - mu[(size_t)c]);     // fl(c - mu), as the kernels form it
+            amax = std::max(amax, std::fabs(v));
+            nn += v * v;
+            n0 += v0 * v0;
+        }
+        nmax = std::max(nmax, nn);
+        nmax0 = std::max(nmax0, n0);
+    }
+    if (!(amax > 0.0 && amax < 1e30)) return VLQ_OK;
+    int e = 0;
+    (void)std::frexp(16384.0 / amax, &e);            // 16384 / amax = m * 2^e, m in [0.5, 1)
+    sc.scale = std::ldexp(1.f, std::max(-100, std::min(100, e - 1)));     // s * amax <= 16384
+    sc.cmax = (float)(std::sqrt(nmax) * 1.0001);
+    sc.cmax0 = (float)(std::sqrt(nmax0) * 1.0001);
+    const int dp = (d + 15) / 16 * 16;
+    TRY(sc.mu.reserve((size_t)d * sizeof(float)));
+    HIP_TRY(hipMemcpy(sc.mu.p, mu.data(), (size_t)d * sizeof(float), hipMemcpyHostToDevice));
+    TRY(sc.half.reserve((size_t)((n + 127) / 128 * 128) * dp * 2));
+    TRY(sc.norm_c.reserve((size_t)n * sizeof(float)));
+    TRY(h->ws_misc.reserve((size_t)n * sizeof(float)));
+    vlq::launch_screen_prep(cent_dev, sc.mu.as<float>(), n, d, sc.scale, sc.half.p, h->ws_misc.as<float>(), sc.norm_c.as<float>(), nullptr,
+                            h->stream);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    sc.ok = true;
+    return VLQ_OK;
+}
+
 int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     if (!h || !centroids) return fail(VLQ_ERR_INVALID, "null argument");
     TRY(set_dev(h));
@@ -696,55 +776,11 @@ int vlq_ivfpq_set_coarse_centroids(vlq_ivfpq_t h, const float* centroids) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_rank = false;
-    h->screen_ok = false;
+    h->screen.ok = false;
     if (h->nlist <= (1 << 17)) {      // O(nlist * d * log nlist) host work; larger indexes keep the list-id order
         std::vector<float> hc((size_t)h->nlist * h->d);
         HIP_TRY(hipMemcpy(hc.data(), h->coarse.p, bytes, hipMemcpyDeviceToHost));
-        // float16 screen of the coarse stage (coarse_screen.hip): the centroids' mean, power-of-two scale from the largest
-        // centred |component|, largest centred norm (rounded up)
-        {
-            std::vector<double> mud((size_t)h->d, 0.0);
-            bool finite = true;
-            for (int i = 0; i < h->nlist; i++)
-                for (int c = 0; c < h->d; c++) {
-                    const double v = hc[(size_t)i * h->d + c];
-                    finite = finite && std::isfinite(v);
-                    mud[(size_t)c] += v;
-                }
-            std::vector<float> mu((size_t)h->d);
-            for (int c = 0; c < h->d; c++) mu[(size_t)c] = finite ? (float)(mud[(size_t)c] / h->nlist) : 0.f;
-            double amax = 0.0, nmax = 0.0, nmax0 = 0.0;
-            for (int i = 0; i < h->nlist && finite; i++) {
-                double nn = 0.0, n0 = 0.0;
-                for (int c = 0; c < h->d; c++) {
-                    const double v0 = hc[(size_t)i * h->d + c];
-                    const double v = (double)(float)(hc[(size_t)i * h->d + c] - mu[(size_t)c]);     // fl(c - mu), as the kernels form it
-                    amax = std::max(amax, std::fabs(v));
-                    nn += v * v;
-                    n0 += v0 * v0;
-                }
-                nmax = std::max(nmax, nn);
-                nmax0 = std::max(nmax0, n0);
-            }
-            h->screen_ok = false;
-            if (finite && amax > 0.0 && amax < 1e30 && h->d <= 128) {
-                int e = 0;
-                (void)std::frexp(16384.0 / amax, &e);            // 16384 / amax = m * 2^e, m in [0.5, 1)
-                h->screen_scale = std::ldexp(1.f, std::max(-100, std::min(100, e - 1)));     // s * amax <= 16384
-                h->screen_cmax = (float)(std::sqrt(nmax) * 1.0001);
-                h->screen_cmax0 = (float)(std::sqrt(nmax0) * 1.0001);
-                const int dp = (h->d + 15) / 16 * 16;
-                TRY(h->coarse_mu.reserve((size_t)h->d * sizeof(float)));
-                HIP_TRY(hipMemcpy(h->coarse_mu.p, mu.data(), (size_t)h->d * sizeof(float), hipMemcpyHostToDevice));
-                TRY(h->coarse_h.reserve((size_t)((h->nlist + 127) / 128 * 128) * dp * 2));
-                TRY(h->cnorm_c.reserve((size_t)h->nlist * sizeof(float)));
-                TRY(h->ws_misc.reserve((size_t)h->nlist * sizeof(float)));
-                vlq::launch_screen_prep(h->coarse.as<float>(), h->coarse_mu.as<float>(), h->nlist, h->d, h->screen_scale, h->coarse_h.p,
-                                        h->ws_misc.as<float>(), h->cnorm_c.as<float>(), nullptr, h->stream);
-                HIP_TRY(hipStreamSynchronize(h->stream));
-                h->screen_ok = true;
-            }
-        }
+        TRY(build_screen(h, hc.data(), h->coarse.as<float>(), h->nlist, h->d, h->screen));
         std::vector<int> rank;
         spatial_list_rank(hc.data(), h->nlist, h->d, rank);
         TRY(h->list_rank.reserve((size_t)h->nlist * sizeof(int)));
@@ -788,6 +824,8 @@ int vlq_ivfpq_set_imi_centroids(vlq_ivfpq_t h, int imi_nbits, const float* centr
     vlq::launch_row_norms(h->imi_cent.as<float>(), 2 * kc, dc, h->imi_norm.as<float>(), h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int m = 0; m < 2; m++)      // float16 screen of each half's distance table (coarse_screen.hip)
+        TRY(build_screen(h, hc.data() + (size_t)m * kc * dc, h->imi_cent.as<float>() + (size_t)m * kc * dc, (int)kc, dc, h->imi_screen[m]));
     h->imi_nbits = imi_nbits;
     h->have_coarse = true;
     h->term2_valid = false;
@@ -851,7 +889,7 @@ int vlq_ivfpq_coarse_screen_state(vlq_ivfpq_t h, int* enabled, uint64_t* rows, u
     if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;
-    if (enabled) *enabled = (h->coarse_screen && h->screen_ok) ? 1 : 0;
+    if (enabled) *enabled = (h->coarse_screen && (h->imi_nbits > 0 ? (h->imi_screen[0].ok && h->imi_screen[1].ok) : h->screen.ok)) ? 1 : 0;
     if (rows) *rows = h->screen_rows_seen;
     if (undecided) *undecided = h->screen_cnt_host ? *h->screen_cnt_host : 0u;
     return VLQ_OK;

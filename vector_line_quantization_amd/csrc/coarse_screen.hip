@@ -464,7 +464,10 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t
 }  // namespace
 
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
-    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 64;
+    // nprobe <= 32: the cut is the nprobe-th smallest of 64 lane minima -- for nprobe towards 64 that is the LARGEST lane minimum,
+    // far above the nprobe-th smallest element (uniform data, 16 384 columns, nprobe 64: 470 columns under the cut, more than a
+    // row's list holds), and every row would be sent to the exact path
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 32;
 }
 
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,

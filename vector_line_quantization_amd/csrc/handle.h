@@ -112,15 +112,17 @@ struct vlq_ivfpq_s {
     int coarse_s_stride = 0;
     // float16 screen of the coarse stage (coarse_screen.hip): half(scale * centroids) [nlist][roundup16(d)], the power-of-two
     // scale, the largest centroid norm; 0 = off, 1 = on (default where the shape allows)
-    DevBuf coarse_h, coarse_mu, cnorm_c, ws_qn_c, ws_xh, ws_xflags, ws_kept, ws_screen_cnt;     // mu = the centroids' mean; *_c: centred
+    // per centroid set (the flat quantizer; each half of a multi-index): half copy in operand order, the centroids' mean,
+    // centred squared norms, the power-of-two scale, max |c - mu|, max |c|
+    struct ScreenSet { DevBuf half, mu, norm_c; float scale = 1.f, cmax = 0.f, cmax0 = 0.f; bool ok = false; };
+    ScreenSet screen, imi_screen[2];
+    DevBuf ws_qn_c, ws_xh, ws_xflags, ws_kept, ws_screen_cnt;
     // rows the screen could not decide (too many / too few columns kept -> done exactly, slowly): counted on the device, mirrored
     // into page-locked memory by an asynchronous copy after every batch and looked at before the next -- an index whose data
     // defeat the bound (0.5 % of the rows) goes back to the matrix path for good
     unsigned int* screen_cnt_host = nullptr;
     uint64_t screen_rows_seen = 0, screen_rows_copied = 0;
-    bool screen_ok = false;
     int coarse_screen = 1;
-    float screen_scale = 1.f, screen_cmax = 0.f, screen_cmax0 = 0.f;       // max |c - mu|, max |c|
     int coarse_filter = 0;        // 1 (VLQ_COARSE_FILTER=1): the filtered coarse stage -- exact, measured SLOWER than the
                                   // matrix path (0.218 against 0.159 ms at C1), kept for A/B only
     // MultiIndexQuantizer coarse quantizer (2 x imi_nbits): codebook [2][kc][d/2], its norms,
