@@ -28,6 +28,7 @@ def make(nlist, d, rng, offset=0.0, spread=1.0):
 
 @pytest.mark.parametrize("nlist,d,nprobe,decides", [(256, 16, 8, True), (1024, 64, 32, True), (2048, 100, 17, True),
                                                     (4096, 128, 32, True), (4096, 96, 2, True), (8192, 8, 32, True),
+                                                    (8192, 32, 64, None), (1024, 32, 64, True),
                                                     # rows wider than 8192 columns: the two-pass streaming keep kernel
                                                     (16384, 64, 32, None), (65536, 16, 8, None)])
 def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
@@ -102,7 +103,7 @@ def test_queries_outside_the_half_range_and_nan_rows():
     assert np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(keys1, keys0)
 
 
-@pytest.mark.parametrize("nbits,d,nprobe", [(8, 128, 16), (10, 64, 32)])
+@pytest.mark.parametrize("nbits,d,nprobe", [(8, 128, 16), (10, 64, 64)])
 def test_multi_index_halves_go_through_the_screen(nbits, d, nprobe):
     """Inverted multi-index: each half's table of 2^nbits sub-centroids is screened like a flat quantizer's; the walk over
     the two sorted lists (MinSumK) sees the same T nearest sub-centroids and distances, so the cells and their sums are
@@ -128,11 +129,11 @@ def test_multi_index_halves_go_through_the_screen(nbits, d, nprobe):
     assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
 
 
-def test_more_than_32_probes_take_the_matrix_path():
+def test_more_than_64_probes_take_the_matrix_path():
     rng = np.random.default_rng(9)
     g, ox, cent = make(1024, 32, rng)
     xq = rng.random((NQ, 32)).astype(np.float32)
-    cd, keys = g.coarse_search(xq, 48)
+    cd, keys = g.coarse_search(xq, 80)
     assert g.coarse_screen_state()[1] == 0                    # no row went through the screen
-    cdo, keyso = ox.coarse_search(xq, 48, canonical=True)
+    cdo, keyso = ox.coarse_search(xq, 80, canonical=True)
     assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)

@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void screen_prep_kernel(const float* __restric
 
 constexpr int kKeepCap = 256;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
 
+// cut: an upper bound of the row's nprobe-th smallest stored value -- the nprobe-th smallest of the 128 values "two smallest
+// elements of every lane" (128 distinct columns; one minimum per lane is too loose a pool once nprobe approaches 64: its
+// nprobe-th smallest is then the LARGEST lane minimum)
+__device__ __forceinline__ void lane_top2(float& m1, float& m2, float x) {
+    const float t = fmaxf(m1, x);
+    m1 = fminf(m1, x);
+    m2 = fminf(m2, t);
+}
+__device__ __forceinline__ float screen_cut(float m1, float m2, int nprobe, int lane) {
+    u64 p[2] = {((u64)f32_to_ordered(m1) << 32) | (uint32_t)lane, ((u64)f32_to_ordered(m2) << 32) | (uint32_t)(64 + lane)};
+    wave_sort_multi<2>(p, lane);
+    const int e = nprobe - 1;
+    return ordered_to_f32((uint32_t)(shfl_u64(e < 64 ? p[0] : p[1], e & 63) >> 32));
+}
+
 // T: the largest stored value (half(sd * approximate distance), read back as float) a column of this row may have and still
 // be kept, from the row's cut (nprobe-th smallest stored lane minimum); *finite = the bound is a number
 __device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float qn0v, float cmax, float cmax0, float c_sub, float inv_sd,
@@ -232,8 +247,8 @@ __device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float 
     return T;
 }
 
-// one wave per row: the row of approximate distances in registers, cut = nprobe-th smallest of the 64 lane minima,
-// columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
+// one wave per row: the row of approximate distances in registers, cut = nprobe-th smallest of the lanes' two smallest
+// elements each, columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
 template <int NV>
 __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
                                                                  const float* __restrict__ qn, const float* __restrict__ qn0,
@@ -253,14 +268,13 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
         const h16x4 hv = row4[min(u * 64 + lane, n4 - 1)];      // clamped; masked below
         v[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
     }
-    float mn = FLT_MAX_F;
+    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
 #pragma unroll
     for (int u = 0; u < NV; u++) {
         if (u * 64 + lane >= n4) v[u] = make_float4(FLT_MAX_F, FLT_MAX_F, FLT_MAX_F, FLT_MAX_F);
-        mn = fminf(mn, fminf(fminf(v[u].x, v[u].y), fminf(v[u].z, v[u].w)));
+        lane_top2(m1, m2, v[u].x); lane_top2(m1, m2, v[u].y); lane_top2(m1, m2, v[u].z); lane_top2(m1, m2, v[u].w);
     }
-    const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
-    const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));      // scaled by sd, rounded to half
+    const float cut_s = screen_cut(m1, m2, nprobe, lane);      // scaled by sd, rounded to half
     bool finite;
     const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];       // NaN / infinite bound, or a query outside the half range
@@ -305,18 +319,19 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _F
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     const h16x4* row4 = reinterpret_cast<const h16x4*>(dist + q * nlist);
     const int n4 = nlist >> 2;
-    float mn = FLT_MAX_F;
+    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
     for (int b4 = 0; b4 < n4; b4 += NV * 64) {
         h16x4 hv[NV];
 #pragma unroll
         for (int u = 0; u < NV; u++) hv[u] = row4[min(b4 + u * 64 + lane, n4 - 1)];
 #pragma unroll
         for (int u = 0; u < NV; u++)
-            if (b4 + u * 64 + lane < n4)
-                mn = fminf(mn, fminf(fminf((float)hv[u][0], (float)hv[u][1]), fminf((float)hv[u][2], (float)hv[u][3])));
+            if (b4 + u * 64 + lane < n4) {
+                lane_top2(m1, m2, (float)hv[u][0]); lane_top2(m1, m2, (float)hv[u][1]);
+                lane_top2(m1, m2, (float)hv[u][2]); lane_top2(m1, m2, (float)hv[u][3]);
+            }
     }
-    const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
-    const float cut_s = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));
+    const float cut_s = screen_cut(m1, m2, nprobe, lane);
     bool finite;
     const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];
@@ -464,10 +479,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t
 }  // namespace
 
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
-    // nprobe <= 32: the cut is the nprobe-th smallest of 64 lane minima -- for nprobe towards 64 that is the LARGEST lane minimum,
-    // far above the nprobe-th smallest element (uniform data, 16 384 columns, nprobe 64: 470 columns under the cut, more than a
-    // row's list holds), and every row would be sent to the exact path
-    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 32;
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 64;
 }
 
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
