@@ -137,3 +137,25 @@ def test_more_than_64_probes_take_the_matrix_path():
     assert g.coarse_screen_state()[1] == 0                    # no row went through the screen
     cdo, keyso = ox.coarse_search(xq, 80, canonical=True)
     assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_near_ties_at_every_scale_around_the_bound(seed):
+    """Clusters of 16 centroids whose mutual distances span 1e-6 .. 1e-1 of their norms -- below, at and above the screen's
+    error bound -- with nprobe cutting through clusters: a column the bound wrongly dropped would show as a wrong key."""
+    rng = np.random.default_rng(100 + seed)
+    nlist, d, nprobe = 1024, 64, 24
+    centres = rng.random((nlist // 16, d)).astype(np.float32) * 4 - 1
+    eps = 10.0 ** rng.uniform(-6, -1, size=(nlist // 16, 1, 1))
+    cent = (centres[:, None, :] * (1 + eps * rng.standard_normal((nlist // 16, 16, d)))).reshape(nlist, d).astype(np.float32)
+    pq = rng.random((4, 256, d // 4)).astype(np.float32)
+    g = vlq.GpuIVFPQ(d, nlist, 4, 8)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    ox = OracleIndex(d, nlist, 4, 8, cent, pq)
+    xq = (centres[rng.integers(0, nlist // 16, NQ)] * (1 + 10.0 ** rng.uniform(-5, -1, size=(NQ, 1)) * rng.standard_normal((NQ, d)))).astype(np.float32)
+    cd, keys = g.coarse_search(xq, nprobe)
+    assert g.coarse_screen_state()[1] == NQ
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)

@@ -11,13 +11,13 @@
 // same distances, same tie order as the matrix path; which columns were screened out never shows.
 //
 // Bound.  q~ = half(s q), c~ = half(s c) with s a power of two chosen from max |c_ij| (round to nearest:
-// |x~ - s x| <= 2^-11 |s x| + 2^-25, the second term covers the subnormal range; a query component that overflows
-// sends its row to the exact path).  The f16 products are exact in fp32 and the MFMA accumulates 128 of them in fp32
+// |x~ - s x| <= 2^-11 |s x| + 2^-25, the second term covers the subnormal range -- budgeted as 2^-14, what flushing
+// subnormal operands to zero would cost; a query component that overflows sends its row to the exact path).  The f16 products are exact in fp32 and the MFMA accumulates 128 of them in fp32
 // (error <= 2^-16 of their absolute sum, generously).  With |q|, |c| the Euclidean norms,
-//     |ip~ / s^2 - <q, c>|  <=  (2^-10 + 2^-16 + 2^-20) |q| |c|  +  2^-25 sqrt(d) (|q| + |c|) / s
+//     |ip~ / s^2 - <q, c>|  <=  (2^-10 + 2^-16 + 2^-20) |q| |c|  +  2^-14 sqrt(d) (|q| + |c|) / s
 // (Cauchy-Schwarz on sum |q_i c_i| and on sum |c_i|).  The exact stage's own fp32 value differs from the real-number
 // distance by at most 2^-15 (|q| + |c|)^2 (128-term fmaf chain, the two norms, three more roundings).  Hence
-//     |approximate - exact|  <=  delta(q) := 1.04 * 2^-9 |q| C + 2^-24 sqrt(d) (|q| + C) / s + 2^-15 (|q| + C)^2,
+//     |approximate - exact|  <=  delta(q) := 1.04 * 2^-9 |q| C + 2^-13 sqrt(d) (|q| + C) / s + 2^-15 (|q| + C)^2,
 // C = the largest centroid norm.  Let cut >= the nprobe-th smallest approximate distance of the row.  nprobe columns
 // have exact distance <= cut + delta, so the nprobe-th smallest EXACT distance is <= cut + delta, and a column whose
 // approximate distance exceeds cut + 2 delta has exact distance > cut + delta: it cannot be among the nprobe nearest,
@@ -521,7 +521,9 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
         default: VLQ_F16G(8); break;
     }
 #undef VLQ_F16G
-    const float c_sub = 5.9604645e-08f /* 2^-24 */ * sqrtf((float)d) / scale * 1.001f;
+    // (2^-13: as if the MFMA flushed subnormal half operands to zero -- 2^-14 per component and side --, which covers rounding
+    // them, 2^-25, with room to spare; either way this term is noise next to the first one on any data worth screening)
+    const float c_sub = 1.220703125e-04f /* 2^-13 */ * sqrtf((float)d) / scale * 1.001f;
     uint16_t* keep = reinterpret_cast<uint16_t*>(keep_ws);
     uint16_t* nkeep = keep + (size_t)nq * kKeepCap;
     dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
