@@ -758,6 +758,9 @@ def main():
         # north_star's "recall@1 >= 0.90" needs a re-ranking stage (IndexIVFPQR, IndexIVFPQ.cpp:1289-1479, what
         # demo_sift1M.cpp:98 selects) that is outside SURVEY.md section 8: 16-byte codes alone do not reach it
         out["config"]["recall_target_met"] = bool(r1 >= 0.90)
+        # the float16 screen of the coarse stage (speed only; csrc/coarse_screen.hip): in use? rows it decided / handed on
+        en, rows_s, und = g.coarse_screen_state()
+        out["config"]["coarse_screen"] = {"enabled": en, "rows_screened": rows_s, "rows_done_exactly_in_full": und}
         if world == 1 and not args.no_host_buffers:
             # the reference drivers' calling convention: queries and results in (pageable) HOST memory;
             # PCIe-inclusive, reported beside `value`, never instead of it
