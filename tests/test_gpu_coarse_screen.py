@@ -29,8 +29,8 @@ def make(nlist, d, rng, offset=0.0, spread=1.0):
 @pytest.mark.parametrize("nlist,d,nprobe,decides", [(256, 16, 8, True), (1024, 64, 32, True), (2048, 100, 17, True),
                                                     (4096, 128, 32, True), (4096, 96, 2, True), (8192, 8, 32, True),
                                                     (8192, 32, 64, None), (1024, 32, 64, True),
-                                                    # rows wider than 8192 columns: the two-pass streaming keep kernel
-                                                    (16384, 64, 32, None), (65536, 16, 8, None)])
+                                                    # rows wider than 8192 columns: tile minima from the distance kernel, tiled keep kernel
+                                                    (16384, 64, 32, None), (65536, 16, 8, None), (131072, 8, 16, None), (16448, 32, 64, None)])
 def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
     rng = np.random.default_rng(nlist + d + nprobe)
     g, ox, cent = make(nlist, d, rng)

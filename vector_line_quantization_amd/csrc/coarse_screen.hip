@@ -55,7 +55,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                               const float* __restrict__ qn, const float* __restrict__ cn,
                                                               _Float16* __restrict__ out, int64_t nq, int nlist, float inv_s2,
-                                                              float sd) {
+                                                              float sd, float* __restrict__ tmin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + (wave >> 1) * 64;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) b[cb][ks] = src[ks * 64];
     }
+    float tmv[2][4];                      // tmin != nullptr: the minimum of this wave's 64 columns per row (row 8g + 4h + (r & 3) of block rb)
     float qnr[2][16];
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
@@ -123,8 +124,29 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
 #pragma unroll
                 for (int i = 0; i < 4; i++) hv[i] = (_Float16)__fmul_rn(sd, v[i]);
                 *reinterpret_cast<h16x4*>(out + row * nlist + col0 + cb * 32 + (r & ~3)) = hv;
+                if (tmin) {
+                    // the row's minimum over the 8 lanes that hold its other columns of this 32-block (lane bits 2..4)
+                    float m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+                    m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 4)));
+                    m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 8)));
+                    m = fminf(m, __uint_as_float(lane_xor_u32(__float_as_uint(m), 16)));
+                    tmv[rb][g] = cb == 0 ? m : fminf(tmv[rb][g], m);
+                }
             }
         }
+    if (tmin) {
+        // stored like the matrix: float(half(sd * minimum)) -- rounding is monotone, so this IS the minimum of the stored halves
+        if (r < 4) {
+            const int ntile = nlist >> 6;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int64_t row = row0 + rb * 32 + 8 * g + 4 * h + r;
+                    if (row < nq) tmin[row * ntile + (col0 >> 6)] = (float)(_Float16)__fmul_rn(sd, tmv[rb][g]);
+                }
+        }
+    }
 }
 
 // exact distance of (query row staged in LDS, centroid col): the fmaf chain of the f32 MFMA kernel over k = 0, 1, 2, ...,
@@ -253,7 +275,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
                                                                  const float* __restrict__ qn, const float* __restrict__ qn0,
                                                                  const unsigned char* __restrict__ flags, float cmax, float cmax0,
-                                                                 float c_sub, float inv_sd, uint16_t* __restrict__ keep,
+                                                                 float c_sub, float inv_sd, uint32_t* __restrict__ keep,
                                                                  uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -279,14 +301,14 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
     const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];       // NaN / infinite bound, or a query outside the half range
     // kept columns: a ballot per register component (most are empty: ~nprobe + 20 of the row's elements pass)
-    uint16_t* out = keep + q * kKeepCap;
+    uint32_t* out = keep + q * kKeepCap;
     int total = 0;
     auto take = [&](float w, uint32_t col) __attribute__((always_inline)) {
         const bool p = w <= T;                               // false for NaN and for +inf (T is finite)
         const u64 m = __ballot(p);
         if (m != 0) {
             const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-            if (p && pos < kKeepCap) out[pos] = (uint16_t)col;
+            if (p && pos < kKeepCap) out[pos] = col;
             total += __popcll(m);
         }
     };
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
 __global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
                                                                         const float* __restrict__ qn, const float* __restrict__ qn0,
                                                                         const unsigned char* __restrict__ flags, float cmax, float cmax0,
-                                                                        float c_sub, float inv_sd, uint16_t* __restrict__ keep,
+                                                                        float c_sub, float inv_sd, uint32_t* __restrict__ keep,
                                                                         uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
     constexpr int NV = 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -335,14 +357,14 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _F
     bool finite;
     const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];
-    uint16_t* out = keep + q * kKeepCap;
+    uint32_t* out = keep + q * kKeepCap;
     int total = 0;
     auto take = [&](float w, uint32_t col, bool in) __attribute__((always_inline)) {
         const bool p = in && w <= T;
         const u64 m = __ballot(p);
         if (m != 0) {
             const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-            if (p && pos < kKeepCap) out[pos] = (uint16_t)col;
+            if (p && pos < kKeepCap) out[pos] = col;
             total += __popcll(m);
         }
     };
@@ -367,19 +389,89 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _F
     }
 }
 
+// rows wider than 8192 columns with tile minima from the distance kernel (one stored value per row and 64-column tile):
+// the cut comes from the tile minima -- every tile minimum is a distinct column's value, so the nprobe-th smallest of the
+// lanes' two smallest tile minima bounds the nprobe-th smallest element --, and only the tiles whose minimum passes the
+// threshold are read: ~nprobe + a few tiles of 128 bytes instead of the whole row (32 KB at 16 384 columns, 256 KB at 2^17).
+// Passing tiles are listed in LDS; 4 lanes then share a tile (16 halves each), 16 tiles per step.
+__global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Float16* __restrict__ dist, const float* __restrict__ tmin,
+                                                                       int64_t nq, int nlist, int nprobe, const float* __restrict__ qn,
+                                                                       const float* __restrict__ qn0, const unsigned char* __restrict__ flags,
+                                                                       float cmax, float cmax0, float c_sub, float inv_sd,
+                                                                       uint32_t* __restrict__ keep, uint16_t* __restrict__ nkeep,
+                                                                       unsigned int* __restrict__ exact_rows) {
+    constexpr int TCAP = 256;                   // passing tiles per row; more -> the row is done exactly
+    __shared__ uint32_t tl[4][TCAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // whole wave; no workgroup barrier below
+    const int ntile = nlist >> 6;
+    const float* tm = tmin + q * ntile;
+    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
+    for (int t0 = 0; t0 < ntile; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < ntile) lane_top2(m1, m2, tm[t]);
+    }
+    const float cut_s = screen_cut(m1, m2, nprobe, lane);
+    bool finite;
+    const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
+    const bool undecided = !finite || flags[q];
+    int npass = 0;
+    for (int t0 = 0; t0 < ntile; t0 += 64) {
+        const int t = t0 + lane;
+        const bool p = t < ntile && tm[t] <= T;
+        const u64 m = __ballot(p);
+        if (m != 0) {
+            const int pos = npass + __popcll(m & ((1ull << lane) - 1ull));
+            if (p && pos < TCAP) tl[wave][pos] = (uint32_t)t;
+            npass += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* out = keep + q * kKeepCap;
+    int total = 0;
+    if (!undecided && npass <= TCAP) {
+        for (int s0 = 0; s0 < npass; s0 += 16) {
+            const int ti = s0 + (lane >> 2);
+            const bool in = ti < npass;
+            const uint32_t tile = in ? tl[wave][ti] : tl[wave][0];
+            // 16 halves of the tile: columns tile * 64 + 16 (lane & 3) + i
+            const h16x8* src = reinterpret_cast<const h16x8*>(dist + q * nlist + (int64_t)tile * 64 + 16 * (lane & 3));
+            const h16x8 v0 = src[0], v1 = src[1];
+            const uint32_t c0 = tile * 64u + 16u * (uint32_t)(lane & 3);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float w = (float)(i < 8 ? v0[i] : v1[i - 8]);
+                const bool p = in && w <= T;
+                const u64 m = __ballot(p);
+                if (m != 0) {
+                    const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                    if (p && pos < kKeepCap) out[pos] = c0 + (uint32_t)i;
+                    total += __popcll(m);
+                }
+            }
+        }
+    }
+    const bool exact_row = undecided || npass > TCAP || total > kKeepCap || total < nprobe;
+    if (lane == 0) {
+        nkeep[q] = exact_row ? (uint16_t)0xffff : (uint16_t)total;
+        if (exact_row && exact_rows) atomicAdd(exact_rows, 1u);
+    }
+}
+
 // one wave per row: exact distances of the kept columns -- a lane owns one column and runs the f32 MFMA kernel's fmaf
 // chain over k = 0, 1, 2, ... (utils.cpp:884's formula around it) -- and the exact (distance, column) selection.  The
 // centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's 64-byte piece (a lane reading
 // its own row would touch 64 cache lines per load instruction), the owner reads its row back component by component
 // (rows padded to 20 floats: 16-byte LDS accesses both ways); the next chunk's pieces are requested before the current one is used.
-__global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t* __restrict__ keep, const uint16_t* __restrict__ nkeep,
+__global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t* __restrict__ keep, const uint16_t* __restrict__ nkeep,
                                                                   int64_t nq, int nlist, int nprobe, float* __restrict__ cdis,
                                                                   int64_t* __restrict__ keys, const float* __restrict__ Q,
                                                                   const float* __restrict__ Cn, const float* __restrict__ qn,
                                                                   const float* __restrict__ cn, int d,
                                                                   unsigned long long* __restrict__ kept_total) {
     __shared__ u64 queue[4][64];
-    __shared__ uint16_t cand[4][kKeepCap];
+    __shared__ uint32_t cand[4][kKeepCap];
     __shared__ __attribute__((aligned(16))) float qrow[4][128];
     __shared__ __attribute__((aligned(16))) float stage[4][64 * 20];      // rows padded to 20 floats: 16-byte accesses both ways
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -387,7 +479,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t
     if (q >= nq) return;                        // whole wave; no workgroup barrier below
     // one round trip for everything the row needs first: the count, the whole (fixed-size) list, the query, its norm
     const int nk = nkeep[q];
-    uint16_t kc[kKeepCap / 64];
+    uint32_t kc[kKeepCap / 64];
 #pragma unroll
     for (int u = 0; u < kKeepCap / 64; u++) kc[u] = keep[q * kKeepCap + u * 64 + lane];
     const float q0 = lane < d ? Q[q * d + lane] : 0.f, q1 = lane + 64 < d ? Q[q * d + lane + 64] : 0.f;
@@ -479,7 +571,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint16_t
 }  // namespace
 
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
-    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= 65536 && nprobe >= 2 && nprobe <= 64;
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= (1 << 20) && nprobe >= 2 && nprobe <= 64;
 }
 
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
@@ -490,11 +582,12 @@ void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float
                        (d + 15) / 16, scale, reinterpret_cast<_Float16*>(out_half), norms, norms_c, flags);
 }
 
-size_t coarse_screen_keep_bytes(int64_t nq) { return (size_t)nq * (kKeepCap + 1) * sizeof(uint16_t); }
+size_t coarse_screen_keep_bytes(int64_t nq) { return (size_t)nq * (kKeepCap * sizeof(uint32_t) + sizeof(uint16_t)); }
 
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
                             const float* qn, const float* cn, const float* qn_c, const float* cn_c,
-                            float* approx /* [roundup128(nq)][nlist] halves */, void* keep_ws, int64_t nq,
+                            float* approx /* [roundup128(nq)][nlist] halves */, float* tmin_ws /* nlist > 8192: [nq][nlist / 64] */,
+                            void* keep_ws, int64_t nq,
                             int nlist, int d, int nprobe, float scale, float cmax, float cmax0, float* cdis, int64_t* keys,
                             unsigned long long* kept_total, unsigned int* exact_rows, hipStream_t s) {
     if (nq <= 0) return;
@@ -509,7 +602,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     const _Float16* qh = reinterpret_cast<const _Float16*>(q_half);
     const _Float16* ch = reinterpret_cast<const _Float16*>(c_half);
     dim3 grid((unsigned)((nq + 127) / 128), (unsigned)((nlist + 127) / 128));
-#define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn_c, cn_c, ah, nq, nlist, inv_s2, sd)
+    float* tmin = nlist > 8192 ? tmin_ws : nullptr;
+#define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn_c, cn_c, ah, nq, nlist, inv_s2, sd, tmin)
     switch (ks) {
         case 1: VLQ_F16G(1); break;
         case 2: VLQ_F16G(2); break;
@@ -524,8 +618,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     // (2^-13: as if the MFMA flushed subnormal half operands to zero -- 2^-14 per component and side --, which covers rounding
     // them, 2^-25, with room to spare; either way this term is noise next to the first one on any data worth screening)
     const float c_sub = 1.220703125e-04f /* 2^-13 */ * sqrtf((float)d) / scale * 1.001f;
-    uint16_t* keep = reinterpret_cast<uint16_t*>(keep_ws);
-    uint16_t* nkeep = keep + (size_t)nq * kKeepCap;
+    uint32_t* keep = reinterpret_cast<uint32_t*>(keep_ws);
+    uint16_t* nkeep = reinterpret_cast<uint16_t*>(keep + (size_t)nq * kKeepCap);
     dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
 #define VLQ_SCR(NV) hipLaunchKernelGGL(coarse_screen_keep_kernel<NV>, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, \
                                        cmax0, c_sub, 1.f / sd, keep, nkeep, exact_rows)
@@ -533,6 +627,9 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     else if (nlist <= 2048) VLQ_SCR(8);
     else if (nlist <= 4096) VLQ_SCR(16);
     else if (nlist <= 8192) VLQ_SCR(32);
+    else if (tmin)
+        hipLaunchKernelGGL(coarse_screen_keep_tiled_kernel, sgrid, block, 0, s, ah, tmin, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
+                           c_sub, 1.f / sd, keep, nkeep, exact_rows);
     else
         hipLaunchKernelGGL(coarse_screen_keep_stream_kernel, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
                            c_sub, 1.f / sd, keep, nkeep, exact_rows);

@@ -42,7 +42,8 @@ void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float
 size_t coarse_screen_keep_bytes(int64_t nq);      // keep_ws of launch_coarse_screened
 // qn / cn: exact squared norms (reference order) of queries / centroids; qn_c / cn_c: of the centred ones; cmax = max |c - mu|
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
-                            const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* approx, void* keep_ws,
+                            const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* approx,
+                            float* tmin_ws /* [nq][nlist / 64] floats when nlist > 8192, else unused */, void* keep_ws,
                             int64_t nq, int nlist, int d, int nprobe, float scale, float cmax, float cmax0 /* max |c| */, float* cdis,
                             int64_t* keys,
                             unsigned long long* kept_total, unsigned int* exact_rows /* += rows the screen could not decide (optional) */,
