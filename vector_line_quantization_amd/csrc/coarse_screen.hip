@@ -327,68 +327,6 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
     }
 }
 
-// the same for rows wider than 8192 columns (up to 65 536: the multi-index halves, the many-list indexes): two passes over
-// the row, 4096 columns at a time -- lane minima and the cut, then the compare + ballot (the second pass reads L2)
-__global__ __launch_bounds__(256) void coarse_screen_keep_stream_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
-                                                                        const float* __restrict__ qn, const float* __restrict__ qn0,
-                                                                        const unsigned char* __restrict__ flags, float cmax, float cmax0,
-                                                                        float c_sub, float inv_sd, uint32_t* __restrict__ keep,
-                                                                        uint16_t* __restrict__ nkeep, unsigned int* __restrict__ exact_rows) {
-    constexpr int NV = 16;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
-    if (q >= nq) return;                        // whole wave; no workgroup barrier below
-    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-    const h16x4* row4 = reinterpret_cast<const h16x4*>(dist + q * nlist);
-    const int n4 = nlist >> 2;
-    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
-    for (int b4 = 0; b4 < n4; b4 += NV * 64) {
-        h16x4 hv[NV];
-#pragma unroll
-        for (int u = 0; u < NV; u++) hv[u] = row4[min(b4 + u * 64 + lane, n4 - 1)];
-#pragma unroll
-        for (int u = 0; u < NV; u++)
-            if (b4 + u * 64 + lane < n4) {
-                lane_top2(m1, m2, (float)hv[u][0]); lane_top2(m1, m2, (float)hv[u][1]);
-                lane_top2(m1, m2, (float)hv[u][2]); lane_top2(m1, m2, (float)hv[u][3]);
-            }
-    }
-    const float cut_s = screen_cut(m1, m2, nprobe, lane);
-    bool finite;
-    const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
-    const bool undecided = !finite || flags[q];
-    uint32_t* out = keep + q * kKeepCap;
-    int total = 0;
-    auto take = [&](float w, uint32_t col, bool in) __attribute__((always_inline)) {
-        const bool p = in && w <= T;
-        const u64 m = __ballot(p);
-        if (m != 0) {
-            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-            if (p && pos < kKeepCap) out[pos] = col;
-            total += __popcll(m);
-        }
-    };
-    for (int b4 = 0; b4 < n4 && total <= kKeepCap; b4 += NV * 64) {
-        h16x4 hv[NV];
-#pragma unroll
-        for (int u = 0; u < NV; u++) hv[u] = row4[min(b4 + u * 64 + lane, n4 - 1)];
-#pragma unroll
-        for (int u = 0; u < NV; u++) {
-            const int i4 = b4 + u * 64 + lane;
-            const uint32_t c0 = (uint32_t)(4 * i4);
-            take((float)hv[u][0], c0 + 0, i4 < n4);
-            take((float)hv[u][1], c0 + 1, i4 < n4);
-            take((float)hv[u][2], c0 + 2, i4 < n4);
-            take((float)hv[u][3], c0 + 3, i4 < n4);
-        }
-    }
-    const bool exact_row = undecided || total > kKeepCap || total < nprobe;
-    if (lane == 0) {
-        nkeep[q] = exact_row ? (uint16_t)0xffff : (uint16_t)total;
-        if (exact_row && exact_rows) atomicAdd(exact_rows, 1u);
-    }
-}
-
 // rows wider than 8192 columns with tile minima from the distance kernel (one stored value per row and 64-column tile):
 // the cut comes from the tile minima -- every tile minimum is a distinct column's value, so the nprobe-th smallest of the
 // lanes' two smallest tile minima bounds the nprobe-th smallest element --, and only the tiles whose minimum passes the
@@ -627,11 +565,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     else if (nlist <= 2048) VLQ_SCR(8);
     else if (nlist <= 4096) VLQ_SCR(16);
     else if (nlist <= 8192) VLQ_SCR(32);
-    else if (tmin)
-        hipLaunchKernelGGL(coarse_screen_keep_tiled_kernel, sgrid, block, 0, s, ah, tmin, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
-                           c_sub, 1.f / sd, keep, nkeep, exact_rows);
     else
-        hipLaunchKernelGGL(coarse_screen_keep_stream_kernel, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
+        hipLaunchKernelGGL(coarse_screen_keep_tiled_kernel, sgrid, block, 0, s, ah, tmin, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
                            c_sub, 1.f / sd, keep, nkeep, exact_rows);
 #undef VLQ_SCR
     hipLaunchKernelGGL(coarse_screen_exact_kernel, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
