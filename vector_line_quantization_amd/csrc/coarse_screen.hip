@@ -4,7 +4,7 @@
 // k = 0, 1, 2, ... in fp32, what the f32 MFMA distance kernel of kernels.hip computes -- spends 120 us of the 150 us
 // coarse stage of the bench batch on 10 GFLOP of f32 MFMA whose results are, all but nprobe of 4096 per row, thrown
 // away.  Here the whole matrix is first computed APPROXIMATELY from float16 copies of the queries and centroids
-// (v_mfma_f32_32x32x16_f16: 16 x the f32 MFMA rate, so that kernel is bound by its 164 MB of output), every column
+// (v_mfma_f32_32x32x16_f16: 16 x the f32 MFMA rate, so that kernel is bound by the matrix it writes), every column
 // that can still belong to the row's nprobe nearest is kept -- with a rigorous bound on |approximate - exact|, below
 // -- and only the kept columns (nprobe + a few) get their EXACT distance, as a k-ascending fmaf chain: bit for bit the
 // value of the f32 MFMA kernel.  The selection over the kept (distance, column) keys is the exact stage's.  Same keys,
@@ -12,8 +12,9 @@
 //
 // Bound.  q~ = half(s q), c~ = half(s c) with s a power of two chosen from max |c_ij| (round to nearest:
 // |x~ - s x| <= 2^-11 |s x| + 2^-25, the second term covers the subnormal range -- budgeted as 2^-14, what flushing
-// subnormal operands to zero would cost; a query component that overflows sends its row to the exact path).  The f16 products are exact in fp32 and the MFMA accumulates 128 of them in fp32
-// (error <= 2^-16 of their absolute sum, generously).  With |q|, |c| the Euclidean norms,
+// subnormal operands to zero would cost; a query component that overflows sends its row to the exact path).  The f16
+// products are exact in fp32 and the MFMA accumulates 128 of them in fp32 (error <= 2^-16 of their absolute sum,
+// generously).  With |q|, |c| the Euclidean norms,
 //     |ip~ / s^2 - <q, c>|  <=  (2^-10 + 2^-16 + 2^-20) |q| |c|  +  2^-14 sqrt(d) (|q| + |c|) / s
 // (Cauchy-Schwarz on sum |q_i c_i| and on sum |c_i|).  The exact stage's own fp32 value differs from the real-number
 // distance by at most 2^-15 (|q| + |c|)^2 (128-term fmaf chain, the two norms, three more roundings).  Hence
@@ -51,6 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // approximate distances: out[row][col] = (qn[row] + cn[col]) - 2 * <q~, c~> / s^2.  A wave owns a 64 x 64 tile and
 // takes its operands straight from global memory in the MFMA's own layout (lane (r, h): row / column r of a 32-block,
 // components 16 ks + 8 h .. + 7 = one 16-byte load): no LDS, no barrier.  The kernel is bound by the matrix it writes.
+// tmin != nullptr (rows wider than 8192 columns): also the minimum of every 64-column tile of a row, [nq][nlist / 64].
 template <int KS>
 __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                               const float* __restrict__ qn, const float* __restrict__ cn,
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
     const int64_t row0 = (int64_t)blockIdx.x * 128 + (wave >> 1) * 64;
     const int col0 = blockIdx.y * 128 + (wave & 1) * 64;
     if (col0 >= nlist) return;                                 // nlist % 64 == 0: a 64-column tile is whole or absent
-    h16x8 a[2][KS], b[2][KS];             // blocked operand order (screen_to_half_kernel): one contiguous KB per load
+    h16x8 a[2][KS], b[2][KS];             // blocked operand order (screen_prep_kernel): one contiguous KB per load
 #pragma unroll
     for (int rb = 0; rb < 2; rb++) {
         const h16x8* src = reinterpret_cast<const h16x8*>(Qh) + ((row0 >> 5) + rb) * (KS * 64) + lane;
