@@ -159,3 +159,67 @@ def test_near_ties_at_every_scale_around_the_bound(seed):
     cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
     assert np.array_equal(bits(cd), bits(cdo))
     assert np.array_equal(keys, keyso)
+
+
+@pytest.mark.parametrize("nlist,d", [(256, 16), (4096, 128), (16384, 64), (131072, 8), (1088, 100)])
+def test_nearest_centroid_screened(nlist, d):
+    """nprobe 1 = the assignment of add / encode: approximate tile minima only, the tiles under the bound exactly -- the
+    matrix path's arg-min by (distance, column), ties at distance 0 included."""
+    rng = np.random.default_rng(nlist + d)
+    g, ox, cent = make(nlist, d, rng)
+    xq = rng.random((NQ, d)).astype(np.float32)
+    xq[:200] = cent[rng.integers(0, nlist, 200)]             # on centroids; the tie run (make()) among them
+    xq[200:240] = cent[3]
+    cd, keys = g.coarse_search(xq, 1)
+    en, rows, und = g.coarse_screen_state()
+    assert rows == NQ
+    cdo, keyso = ox.coarse_search(xq, 1, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+    g.set_coarse_screen(0)
+    cd0, keys0 = g.coarse_search(xq, 1)
+    assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
+
+
+def test_add_goes_through_the_screen_and_fills_the_same_lists():
+    rng = np.random.default_rng(11)
+    nlist, d, M = 512, 64, 16
+    cent = rng.random((nlist, d)).astype(np.float32)
+    pq = (0.2 * rng.standard_normal((M, 256, d // M))).astype(np.float32)
+    xb = (cent[rng.integers(0, nlist, 6000)] + 0.05 * rng.standard_normal((6000, d))).astype(np.float32)
+    lists = []
+    for screen in (1, 0):
+        g = vlq.GpuIVFPQ(d, nlist, M, 8)
+        g.set_coarse_centroids(cent)
+        g.set_pq_centroids(pq)
+        g.set_coarse_screen(screen)
+        g.add(xb)
+        assert (g.coarse_screen_state()[1] > 0) == bool(screen)
+        lists.append([g.get_list(i) for i in range(nlist)])
+    for (c1, i1), (c0, i0) in zip(*lists):
+        assert np.array_equal(i1, i0) and np.array_equal(c1, c0)
+    ox = OracleIndex(d, nlist, M, 8, cent, pq)
+    ox.add(xb, None, canonical=True)
+    off = ox.list_offsets
+    for i in range(nlist):
+        assert np.array_equal(lists[0][i][1], ox.ids[off[i]:off[i + 1]])
+        assert np.array_equal(lists[0][i][0], ox.codes[off[i]:off[i + 1]])
+
+
+def test_multi_index_assignment_screened():
+    rng = np.random.default_rng(12)
+    nbits, d, M = 8, 128, 16
+    kc, dc = 1 << nbits, d // 2
+    imi = rng.random((2, kc, dc), dtype=np.float32)
+    imi[1, 9:30] = imi[1, 4]
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.4).astype(np.float32)
+    xq = rng.random((NQ, d), dtype=np.float32)
+    xq[:50, dc:] = imi[1, 4]
+    ox = OracleIndex(d, kc * kc, M, 8, None, pq, imi_centroids=imi, imi_nbits=nbits)
+    g = vlq.GpuIVFPQ(d, kc * kc, M, 8)
+    g.set_imi_centroids(nbits, imi)
+    g.set_pq_centroids(pq)
+    cd, keys = g.coarse_search(xq, 1)
+    assert g.coarse_screen_state()[1] == 2 * NQ
+    cdo, keyso = ox.coarse_search(xq, 1, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)

@@ -136,6 +136,22 @@ int64_t query_page(vlq_ivfpq_t h) {
     return page;
 }
 
+// the screen's "rows it could not decide" counter: on the device, mirrored into page-locked host memory behind every batch
+static int screen_counters(vlq_ivfpq_t h) {
+    if (h->screen_cnt_host) return VLQ_OK;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
+    *h->screen_cnt_host = 0;
+    TRY(h->ws_screen_cnt.reserve(8));
+    HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream));
+    return VLQ_OK;
+}
+static int screen_counters_copy(vlq_ivfpq_t h, int64_t n) {
+    h->screen_rows_seen += (uint64_t)n;
+    HIP_TRY(hipMemcpyAsync(h->screen_cnt_host, h->ws_screen_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
+    h->screen_rows_copied = h->screen_rows_seen;
+    return VLQ_OK;
+}
+
 // coarse stage of one page; keep_matrix: the caller reads the [n][nlist] distance matrix in h->ws_dist
 // afterwards (VLQ line select)
 int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float* cdis_dev,
@@ -181,15 +197,28 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
     if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
+    if (argmin && !zero_qnorm && h->coarse_screen && h->screen.ok && n >= 2048 && vlq::coarse_screen_nn_shape_ok(h->nlist, h->d)) {
+        // 1-NN (add / encode): approximate tile minima only, the tiles under the bound exactly (coarse_screen.hip)
+        TRY(screen_counters(h));
+        const int dp = (h->d + 15) / 16 * 16;
+        TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
+        TRY(h->ws_xflags.reserve((size_t)n));
+        TRY(h->ws_qn_c.reserve((size_t)n * sizeof(float)));
+        TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * 8));
+        vlq::launch_screen_prep(x_dev, h->screen.mu.as<float>(), n, h->d, h->screen.scale, h->ws_xh.p, h->ws_qn.as<float>(),
+                                h->ws_qn_c.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
+        vlq::launch_coarse_screened_nn(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->screen.half.p,
+                                       h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_qn_c.as<float>(), h->screen.norm_c.as<float>(),
+                                       h->ws_tmin.as<float>(), n, h->nlist, h->d, h->screen.scale, h->screen.cmax, h->screen.cmax0, cdis_dev,
+                                       keys_dev, h->ws_screen_cnt.as<unsigned int>(), h->stream);
+        TRY(screen_counters_copy(h, n));
+        HIP_TRY(hipGetLastError());
+        return VLQ_OK;
+    }
     // (below ~2000 rows the screen's five short kernels cost more than the matrix path's two: 1250 rows 46 against 40 us)
     if (!direct && !keep_matrix && !argmin && !zero_qnorm && h->coarse_screen && h->screen.ok && n >= 2048 &&
         vlq::coarse_screen_shape_ok(h->nlist, h->d, nprobe)) {
-        if (!h->screen_cnt_host) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
-            *h->screen_cnt_host = 0;
-            TRY(h->ws_screen_cnt.reserve(8));
-            HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream));
-        }
+        TRY(screen_counters(h));
         // float16 screen (coarse_screen.hip): approximate matrix -> kept columns -> exact fmaf chains -> exact select
         const int dp = (h->d + 15) / 16 * 16;
         TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
@@ -210,9 +239,7 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
                                     h->d, nprobe, h->screen.scale, h->screen.cmax, h->screen.cmax0, cdis_dev, keys_dev,
                                     h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
                                     h->stream);
-        h->screen_rows_seen += (uint64_t)n;
-        HIP_TRY(hipMemcpyAsync(h->screen_cnt_host, h->ws_screen_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
-        h->screen_rows_copied = h->screen_rows_seen;
+        TRY(screen_counters_copy(h, n));
         HIP_TRY(hipGetLastError());
         return VLQ_OK;
     }
@@ -274,17 +301,32 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
         float* tmin = nullptr;
         bool argmin = false;
+        if (dc >= 16 && T == 1 && h->coarse_screen && h->imi_screen[m].ok && n >= 2048 && vlq::coarse_screen_nn_shape_ok(kc, dc)) {
+            // the assignment of add / encode: nearest sub-centroid of each half, tile minima only (coarse_screen.hip)
+            const vlq_ivfpq_s::ScreenSet& sc = h->imi_screen[m];
+            const int dp = (dc + 15) / 16 * 16;
+            TRY(screen_counters(h));
+            TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
+            TRY(h->ws_xflags.reserve((size_t)n));
+            TRY(h->ws_qn.reserve((size_t)n * 4));
+            TRY(h->ws_qn_c.reserve((size_t)n * 4));
+            TRY(h->ws_tmin.reserve((size_t)n * (kc / 64) * 8));
+            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
+            vlq::launch_screen_prep(sub, sc.mu.as<float>(), n, dc, sc.scale, h->ws_xh.p, h->ws_qn.as<float>(), h->ws_qn_c.as<float>(),
+                                    h->ws_xflags.as<unsigned char>(), h->stream);
+            vlq::launch_coarse_screened_nn(sub, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), cent, sc.half.p, h->ws_qn.as<float>(),
+                                           h->imi_norm.as<float>() + (size_t)m * kc, h->ws_qn_c.as<float>(), sc.norm_c.as<float>(),
+                                           h->ws_tmin.as<float>(), n, kc, dc, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m],
+                                           h->ws_screen_cnt.as<unsigned int>(), h->stream);
+            TRY(screen_counters_copy(h, n));
+            continue;
+        }
         if (dc >= 16 && h->coarse_screen && h->imi_screen[m].ok && n >= 2048 && vlq::coarse_screen_shape_ok(kc, dc, T)) {
             // float16 screen of this half's table (coarse_screen.hip): approximate half matrix in tab[m], kept columns, exact
             // fmaf chains, exact select -- the T nearest sub-centroids and their distances as the matrix path returns them
             const vlq_ivfpq_s::ScreenSet& sc = h->imi_screen[m];
             const int dp = (dc + 15) / 16 * 16;
-            if (!h->screen_cnt_host) {
-                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->screen_cnt_host), 8, hipHostMallocDefault));
-                *h->screen_cnt_host = 0;
-                TRY(h->ws_screen_cnt.reserve(8));
-                HIP_TRY(hipMemsetAsync(h->ws_screen_cnt.p, 0, 8, h->stream));
-            }
+            TRY(screen_counters(h));
             TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
             TRY(h->ws_xflags.reserve((size_t)n));
             TRY(h->ws_qn.reserve((size_t)n * 4));
@@ -298,9 +340,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
                                         h->imi_norm.as<float>() + (size_t)m * kc, h->ws_qn_c.as<float>(), sc.norm_c.as<float>(), tab[m],
                                         kc > 8192 ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
                                         h->ws_screen_cnt.as<unsigned int>(), h->stream);
-            h->screen_rows_seen += (uint64_t)n;
-            HIP_TRY(hipMemcpyAsync(h->screen_cnt_host, h->ws_screen_cnt.p, 4, hipMemcpyDeviceToHost, h->stream));
-            h->screen_rows_copied = h->screen_rows_seen;
+            TRY(screen_counters_copy(h, n));
             continue;
         }
         if (dc < 16) {

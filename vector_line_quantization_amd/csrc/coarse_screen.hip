@@ -52,7 +52,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // approximate distances: out[row][col] = (qn[row] + cn[col]) - 2 * <q~, c~> / s^2.  A wave owns a 64 x 64 tile and
 // takes its operands straight from global memory in the MFMA's own layout (lane (r, h): row / column r of a 32-block,
 // components 16 ks + 8 h .. + 7 = one 16-byte load): no LDS, no barrier.  The kernel is bound by the matrix it writes.
-// tmin != nullptr (rows wider than 8192 columns): also the minimum of every 64-column tile of a row, [nq][nlist / 64].
+// tmin != nullptr (rows wider than 8192 columns): also the minimum of every 64-column tile of a row, [nq][nlist / 64];
+// out == nullptr: ONLY those minima, in fp32 (the 1-NN screen of the assignment).
 template <int KS>
 __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                               const float* __restrict__ qn, const float* __restrict__ cn,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
                 h16x4 hv;
 #pragma unroll
                 for (int i = 0; i < 4; i++) hv[i] = (_Float16)__fmul_rn(sd, v[i]);
-                *reinterpret_cast<h16x4*>(out + row * nlist + col0 + cb * 32 + (r & ~3)) = hv;
+                if (out) *reinterpret_cast<h16x4*>(out + row * nlist + col0 + cb * 32 + (r & ~3)) = hv;
                 if (tmin) {
                     // the row's minimum over the 8 lanes that hold its other columns of this 32-block (lane bits 2..4)
                     float m = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int64_t row = row0 + rb * 32 + 8 * g + 4 * h + r;
-                    if (row < nq) tmin[row * ntile + (col0 >> 6)] = (float)(_Float16)__fmul_rn(sd, tmv[rb][g]);
+                    // (out == nullptr: the 1-NN screen, minima only -- kept in fp32, no matrix at all)
+                    if (row < nq) tmin[row * ntile + (col0 >> 6)] = out ? (float)(_Float16)__fmul_rn(sd, tmv[rb][g]) : tmv[rb][g];
                 }
         }
     }
@@ -241,6 +243,17 @@ __device__ __forceinline__ float screen_cut(float m1, float m2, int nprobe, int 
     wave_sort_multi<2>(p, lane);
     const int e = nprobe - 1;
     return ordered_to_f32((uint32_t)(shfl_u64(e < 64 ? p[0] : p[1], e & 63) >> 32));
+}
+
+// smallest of a float over the wave, as bits (DPP inside rows of 16, readlane across; NaN inputs lose to numbers: fminf)
+__device__ __forceinline__ uint32_t wave_min_ordered(float v) {
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return __float_as_uint(fminf(fminf(a, b), fminf(c, e)));
 }
 
 // T: the largest stored value (half(sd * approximate distance), read back as float) a column of this row may have and still
@@ -399,6 +412,59 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Fl
     }
 }
 
+// <q, c_col> for up to 64 columns at once, lane l for column col_of(l) (l < ncand), as the f32 MFMA kernel accumulates it: an
+// fmaf chain over k = 0, 1, 2, ...  The centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's
+// 64-byte piece (a lane reading its own row would touch 64 cache lines per load instruction), the owner reads its row back
+// (rows padded to 20 floats: 16-byte LDS accesses both ways).  qrow: the query in LDS; st: 64 x 20 floats of LDS per wave.
+template <typename ColOf>
+__device__ __forceinline__ float exact_ip_batch(const float* __restrict__ Cn, int d, ColOf col_of, int ncand, const float* qrow, float* st,
+                                                int lane) {
+    const int nch = (d + 15) >> 4;
+    // pieces of 4 chunks (64 components) are in flight at a time: a load's latency here is ~2 us, the chain
+    // of one chunk takes a tenth of that
+    float4 piece[4][4];
+    // the four rows this lane helps to fetch (lanes 4a .. 4a+3: row a + 16 j), their pieces of a chunk 64 bytes apart
+    const float* rp[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int ci = (lane >> 2) + 16 * j;
+        rp[j] = Cn + (size_t)(ci < ncand ? col_of(ci) : col_of(0)) * d + 4 * (lane & 3);
+    }
+    auto fetch = [&](int ch, float4 (&dst)[4]) __attribute__((always_inline)) {
+        const bool ld = 16 * ch + 4 * (lane & 3) < d;        // (rows past ncand read row 0 of the batch: never used)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            dst[j] = ld ? *reinterpret_cast<const float4*>(rp[j] + 16 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float ip = 0.f;
+    for (int ch0 = 0; ch0 < nch; ch0 += 4) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) fetch(ch0 + c4, piece[c4]);      // (chunks past d load nothing)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+            const int ch = ch0 + c4;
+            if (ch < nch) {                    // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4*>(st + ((lane >> 2) + 16 * j) * 20 + 4 * (lane & 3)) = piece[c4][j];
+                __builtin_amdgcn_wave_barrier();
+                const float* mine = st + lane * 20;
+                const int k0 = 16 * ch, kn = min(16, d - k0);
+                for (int kk = 0; kk < kn; kk += 4) {
+                    const float4 qv = *reinterpret_cast<const float4*>(qrow + k0 + kk);
+                    const float4 cv = *reinterpret_cast<const float4*>(mine + kk);
+                    ip = __fmaf_rn(qv.x, cv.x, ip);
+                    ip = __fmaf_rn(qv.y, cv.y, ip);
+                    ip = __fmaf_rn(qv.z, cv.z, ip);
+                    ip = __fmaf_rn(qv.w, cv.w, ip);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    return ip;
+}
+
 // one wave per row: exact distances of the kept columns -- a lane owns one column and runs the f32 MFMA kernel's fmaf
 // chain over k = 0, 1, 2, ... (utils.cpp:884's formula around it) -- and the exact (distance, column) selection.  The
 // centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's 64-byte piece (a lane reading
@@ -435,54 +501,12 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
     __builtin_amdgcn_wave_barrier();
     if (!exact_row) {
         float* st = stage[wave];
-        const int nch = (d + 15) >> 4;
         for (int c0 = 0; c0 < total; c0 += 64) {
             const int ncand = min(64, total - c0);
             const bool valid = lane < ncand;
             const uint32_t col = valid ? cand[wave][c0 + lane] : 0u;
             const float cnv = cn[col];             // (in flight with the pieces)
-            // pieces of 4 chunks (64 components) are in flight at a time: a load's latency here is ~2 us, the chain
-            // of one chunk takes a tenth of that
-            float4 piece[4][4];
-            // the four rows this lane helps to fetch (lanes 4a .. 4a+3: row a + 16 j), their pieces of a chunk 64 bytes apart
-            const float* rp[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ci = (lane >> 2) + 16 * j;
-                rp[j] = Cn + (size_t)(ci < ncand ? cand[wave][c0 + ci] : cand[wave][c0]) * d + 4 * (lane & 3);
-            }
-            auto fetch = [&](int ch, float4 (&dst)[4]) __attribute__((always_inline)) {
-                const bool ld = 16 * ch + 4 * (lane & 3) < d;        // (rows past ncand read row 0 of the batch: never used)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    dst[j] = ld ? *reinterpret_cast<const float4*>(rp[j] + 16 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            };
-            float ip = 0.f;
-            for (int ch0 = 0; ch0 < nch; ch0 += 4) {
-#pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) fetch(ch0 + c4, piece[c4]);      // (chunks past d load nothing)
-#pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {
-                    const int ch = ch0 + c4;
-                    if (ch < nch) {                    // wave-uniform
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            *reinterpret_cast<float4*>(st + ((lane >> 2) + 16 * j) * 20 + 4 * (lane & 3)) = piece[c4][j];
-                        __builtin_amdgcn_wave_barrier();
-                        const float* mine = st + lane * 20;
-                        const int k0 = 16 * ch, kn = min(16, d - k0);
-                        for (int kk = 0; kk < kn; kk += 4) {
-                            const float4 qv = *reinterpret_cast<const float4*>(qrow[wave] + k0 + kk);
-                            const float4 cv = *reinterpret_cast<const float4*>(mine + kk);
-                            ip = __fmaf_rn(qv.x, cv.x, ip);
-                            ip = __fmaf_rn(qv.y, cv.y, ip);
-                            ip = __fmaf_rn(qv.z, cv.z, ip);
-                            ip = __fmaf_rn(qv.w, cv.w, ip);
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
+            const float ip = exact_ip_batch(Cn, d, [&](int ci) { return cand[wave][c0 + ci]; }, ncand, qrow[wave], st, lane);
             const float x = __fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip));
             // columns do not arrive in increasing order: equal distances are queued, the key decides
             sel.template offer<false>(x, col, valid);
@@ -505,6 +529,73 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
         const bool miss = key == kMaxKey;
         cdis[q * nprobe + lane] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
         keys[q * nprobe + lane] = miss ? -1 : (int64_t)(uint32_t)key;
+    }
+}
+
+// 1-NN (the assignment of add / encode; nprobe == 1): no matrix.  One wave per row: the smallest approximate tile minimum
+// is the cut; a tile whose approximate minimum exceeds cut + 2 delta holds no column that could be the nearest or tie with
+// it (its exact distances all exceed cut + delta >= the nearest's); the 64 columns of every other tile -- one or two
+// tiles, usually -- get their exact distances, and the row's answer is the smallest (distance, column) key, the matrix
+// path's arg-min.  More than 8 tiles under the bound, or a bound that is not a number: the whole row exactly.
+__global__ __launch_bounds__(256) void coarse_screen_nn_kernel(const float* __restrict__ tmin, int64_t nq, int nlist, float* __restrict__ cdis,
+                                                               int64_t* __restrict__ keys, const float* __restrict__ Q,
+                                                               const float* __restrict__ Cn, const float* __restrict__ qn,
+                                                               const float* __restrict__ cn, const float* __restrict__ qn_c,
+                                                               const unsigned char* __restrict__ flags, int d, float cmax, float cmax0,
+                                                               float c_sub, unsigned int* __restrict__ exact_rows) {
+    constexpr int TCAP = 8;
+    __shared__ uint32_t tl[4][TCAP];
+    __shared__ __attribute__((aligned(16))) float qrow[4][128];
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * 20];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;                        // whole wave; no workgroup barrier below
+    const int ntile = nlist >> 6;
+    const float* tm = tmin + q * ntile;
+    const float q0 = lane < d ? Q[q * d + lane] : 0.f, q1 = lane + 64 < d ? Q[q * d + lane + 64] : 0.f;
+    const float qnv = qn[q];
+    float mn = FLT_MAX_F;
+    for (int t = lane; t < ntile; t += 64) mn = fminf(mn, tm[t]);
+    const float cut = __uint_as_float(wave_min_ordered(mn));
+    bool finite;
+    const float T = screen_threshold(cut, qn_c[q], qnv, cmax, cmax0, c_sub, 1.f, &finite);      // (fp32 minima: sd = 1)
+    qrow[wave][lane] = q0;
+    qrow[wave][lane + 64] = q1;
+    int npass = 0;
+    for (int t0 = 0; t0 < ntile; t0 += 64) {
+        const int t = t0 + lane;
+        const bool p = t < ntile && tm[t] <= T;
+        const u64 m = __ballot(p);
+        if (m != 0) {
+            const int pos = npass + __popcll(m & ((1ull << lane) - 1ull));
+            if (p && pos < TCAP) tl[wave][pos] = (uint32_t)t;
+            npass += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool exact_row = !finite || flags[q] || npass > TCAP || npass < 1;
+    u64 best = kMaxKey;
+    if (!exact_row) {
+        for (int i = 0; i < npass; i++) {
+            const uint32_t col = tl[wave][i] * 64u + (uint32_t)lane;
+            const float cnv = cn[col];
+            const float ip = exact_ip_batch(Cn, d, [&](int ci) { return tl[wave][i] * 64u + (uint32_t)ci; }, 64, qrow[wave], stage[wave], lane);
+            best = umin64(best, make_key(__fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip)), col));
+        }
+    } else {
+        for (int j0 = 0; j0 < nlist; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nlist) best = umin64(best, make_key(exact_distance(qrow[wave], Cn + (size_t)j * d, d, qnv, cn[j]), (uint32_t)j));
+        }
+        if (exact_rows && lane == 0) atomicAdd(exact_rows, 1u);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) best = umin64(best, shfl_xor_u64(best, sft));
+    if (lane == 0) {
+        const float dis = ordered_to_f32((uint32_t)(best >> 32));
+        const bool miss = !(dis < FLT_MAX_F);      // the reference's heap starts at FLT_MAX and admits only dis < top (Heap.h:76-78)
+        cdis[q] = miss ? FLT_MAX_F : dis;
+        keys[q] = miss ? -1 : (int64_t)(uint32_t)best;
     }
 }
 
@@ -573,6 +664,38 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
 #undef VLQ_SCR
     hipLaunchKernelGGL(coarse_screen_exact_kernel, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
                        kept_total);
+}
+
+bool coarse_screen_nn_shape_ok(int nlist, int d) {
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= (1 << 20);
+}
+
+void launch_coarse_screened_nn(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
+                               const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* tmin_ws, int64_t nq, int nlist,
+                               int d, float scale, float cmax, float cmax0, float* cdis, int64_t* keys, unsigned int* exact_rows,
+                               hipStream_t s) {
+    if (nq <= 0) return;
+    const int ks = (d + 15) / 16;
+    const float inv_s2 = 1.f / (scale * scale);
+    const _Float16* qh = reinterpret_cast<const _Float16*>(q_half);
+    const _Float16* ch = reinterpret_cast<const _Float16*>(c_half);
+    dim3 grid((unsigned)((nq + 127) / 128), (unsigned)((nlist + 127) / 128));
+#define VLQ_F16M(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn_c, cn_c, (_Float16*)nullptr, nq, nlist, inv_s2, \
+                                       1.f, tmin_ws)
+    switch (ks) {
+        case 1: VLQ_F16M(1); break;
+        case 2: VLQ_F16M(2); break;
+        case 3: VLQ_F16M(3); break;
+        case 4: VLQ_F16M(4); break;
+        case 5: VLQ_F16M(5); break;
+        case 6: VLQ_F16M(6); break;
+        case 7: VLQ_F16M(7); break;
+        default: VLQ_F16M(8); break;
+    }
+#undef VLQ_F16M
+    const float c_sub = 1.220703125e-04f /* 2^-13 */ * sqrtf((float)d) / scale * 1.001f;
+    hipLaunchKernelGGL(coarse_screen_nn_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, tmin_ws, nq, nlist, cdis, keys, q, c, qn, cn,
+                       qn_c, q_flags, d, cmax, cmax0, c_sub, exact_rows);
 }
 
 }  // namespace vlq

@@ -39,6 +39,12 @@ bool coarse_screen_shape_ok(int nlist, int d, int nprobe);
 // |x|^2 (reference order), |x - mu|^2 and the half-range flag of scale * (x - mu) (flags optional)
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
                         unsigned char* flags, hipStream_t s);
+// nprobe == 1 (the assignment of add / encode): tile minima only (tmin_ws [nq][nlist / 64] floats), no matrix
+bool coarse_screen_nn_shape_ok(int nlist, int d);
+void launch_coarse_screened_nn(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
+                               const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* tmin_ws, int64_t nq, int nlist,
+                               int d, float scale, float cmax, float cmax0, float* cdis, int64_t* keys, unsigned int* exact_rows,
+                               hipStream_t s);
 size_t coarse_screen_keep_bytes(int64_t nq);      // keep_ws of launch_coarse_screened
 // qn / cn: exact squared norms (reference order) of queries / centroids; qn_c / cn_c: of the centred ones; cmax = max |c - mu|
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
