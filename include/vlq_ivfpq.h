@@ -140,7 +140,7 @@ int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode);
 
 /* Float16 screen of the coarse stage -- SPEED ONLY, results are identical with and without it (csrc/coarse_screen.hip):
  * batches of 2048 queries and more on coarse quantizers of 256 .. 2^20 centroids (flat, or each half of a multi-index;
- * d <= 128, nprobe 1 .. 64: searches, and the assignment of add / encode) first get an
+ * d <= 128, nprobe 1 .. 128: searches, and the assignment of add / encode) first get an
  * APPROXIMATE distance matrix from half copies of queries and centroids; a rigorous bound on |approximate - exact| keeps
  * every column that can still be among a row's nprobe nearest, and only those get the exact fp32 distance of the matrix
  * path (the same k-ascending fmaf chain), then the same (distance, column) selection.  Rows the bound cannot decide are

@@ -28,9 +28,10 @@ def make(nlist, d, rng, offset=0.0, spread=1.0):
 
 @pytest.mark.parametrize("nlist,d,nprobe,decides", [(256, 16, 8, True), (1024, 64, 32, True), (2048, 100, 17, True),
                                                     (4096, 128, 32, True), (4096, 96, 2, True), (8192, 8, 32, True),
-                                                    (8192, 32, 64, None), (1024, 32, 64, True),
+                                                    (8192, 32, 64, None), (1024, 32, 64, True), (4096, 64, 128, None), (1024, 32, 100, None),
                                                     # rows wider than 8192 columns: tile minima from the distance kernel, tiled keep kernel
-                                                    (16384, 64, 32, None), (65536, 16, 8, None), (131072, 8, 16, None), (16448, 32, 64, None)])
+                                                    (16384, 64, 32, None), (65536, 16, 8, None), (131072, 8, 16, None), (16448, 32, 64, None),
+                                                    (131072, 16, 128, None), (8256, 32, 128, None)])
 def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
     rng = np.random.default_rng(nlist + d + nprobe)
     g, ox, cent = make(nlist, d, rng)
@@ -129,13 +130,13 @@ def test_multi_index_halves_go_through_the_screen(nbits, d, nprobe):
     assert np.array_equal(bits(cd0), bits(cd)) and np.array_equal(keys0, keys)
 
 
-def test_more_than_64_probes_take_the_matrix_path():
+def test_more_than_128_probes_take_the_matrix_path():
     rng = np.random.default_rng(9)
     g, ox, cent = make(1024, 32, rng)
     xq = rng.random((NQ, 32)).astype(np.float32)
-    cd, keys = g.coarse_search(xq, 80)
+    cd, keys = g.coarse_search(xq, 130)
     assert g.coarse_screen_state()[1] == 0                    # no row went through the screen
-    cdo, keyso = ox.coarse_search(xq, 80, canonical=True)
+    cdo, keyso = ox.coarse_search(xq, 130, canonical=True)
     assert np.array_equal(bits(cd), bits(cdo)) and np.array_equal(keys, keyso)
 
 

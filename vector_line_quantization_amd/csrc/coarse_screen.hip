@@ -228,21 +228,31 @@ __global__ __launch_bounds__(256) void screen_prep_kernel(const float* __restric
     if (flags) flags[row0 + t] = bad ? 1 : 0;
 }
 
-constexpr int kKeepCap = 256;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
+constexpr int kKeepCap = 512;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
 
-// cut: an upper bound of the row's nprobe-th smallest stored value -- the nprobe-th smallest of the 128 values "two smallest
-// elements of every lane" (128 distinct columns; one minimum per lane is too loose a pool once nprobe approaches 64: its
-// nprobe-th smallest is then the LARGEST lane minimum)
-__device__ __forceinline__ void lane_top2(float& m1, float& m2, float x) {
-    const float t = fmaxf(m1, x);
-    m1 = fminf(m1, x);
-    m2 = fminf(m2, t);
+// cut: an upper bound of the row's nprobe-th smallest stored value -- the nprobe-th smallest of the 64 MT values "MT smallest
+// elements of every lane" (distinct columns; one minimum per lane is too loose a pool once nprobe approaches 64: its
+// nprobe-th smallest is then the LARGEST lane minimum).  MT = 2 for nprobe <= 64, 4 for nprobe <= 128.
+template <int MT>
+__device__ __forceinline__ void lane_top(float (&m)[MT], float x) {
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const float t = fmaxf(m[i], x);
+        m[i] = fminf(m[i], x);
+        x = t;
+    }
 }
-__device__ __forceinline__ float screen_cut(float m1, float m2, int nprobe, int lane) {
-    u64 p[2] = {((u64)f32_to_ordered(m1) << 32) | (uint32_t)lane, ((u64)f32_to_ordered(m2) << 32) | (uint32_t)(64 + lane)};
-    wave_sort_multi<2>(p, lane);
+template <int MT>
+__device__ __forceinline__ float screen_cut(const float (&m)[MT], int nprobe, int lane) {
+    u64 p[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) p[i] = ((u64)f32_to_ordered(m[i]) << 32) | (uint32_t)(64 * i + lane);
+    wave_sort_multi<MT>(p, lane);
     const int e = nprobe - 1;
-    return ordered_to_f32((uint32_t)(shfl_u64(e < 64 ? p[0] : p[1], e & 63) >> 32));
+    u64 row = p[0];
+#pragma unroll
+    for (int i = 1; i < MT; i++) row = (e >> 6) == i ? p[i] : row;
+    return ordered_to_f32((uint32_t)(shfl_u64(row, e & 63) >> 32));
 }
 
 // smallest of a float over the wave, as bits (DPP inside rows of 16, readlane across; NaN inputs lose to numbers: fminf)
@@ -286,7 +296,7 @@ __device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float 
 
 // one wave per row: the row of approximate distances in registers, cut = nprobe-th smallest of the lanes' two smallest
 // elements each, columns at or below cut + 2 delta(q) are kept: keep[q][0 .. nkeep[q]) (nkeep = 0xffff: the whole row exactly)
-template <int NV>
+template <int NV, int MT>
 __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16* __restrict__ dist, int64_t nq, int nlist, int nprobe,
                                                                  const float* __restrict__ qn, const float* __restrict__ qn0,
                                                                  const unsigned char* __restrict__ flags, float cmax, float cmax0,
@@ -305,13 +315,15 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
         const h16x4 hv = row4[min(u * 64 + lane, n4 - 1)];      // clamped; masked below
         v[u] = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
     }
-    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
+    float mt[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) mt[i] = FLT_MAX_F;
 #pragma unroll
     for (int u = 0; u < NV; u++) {
         if (u * 64 + lane >= n4) v[u] = make_float4(FLT_MAX_F, FLT_MAX_F, FLT_MAX_F, FLT_MAX_F);
-        lane_top2(m1, m2, v[u].x); lane_top2(m1, m2, v[u].y); lane_top2(m1, m2, v[u].z); lane_top2(m1, m2, v[u].w);
+        lane_top<MT>(mt, v[u].x); lane_top<MT>(mt, v[u].y); lane_top<MT>(mt, v[u].z); lane_top<MT>(mt, v[u].w);
     }
-    const float cut_s = screen_cut(m1, m2, nprobe, lane);      // scaled by sd, rounded to half
+    const float cut_s = screen_cut<MT>(mt, nprobe, lane);      // scaled by sd, rounded to half
     bool finite;
     const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];       // NaN / infinite bound, or a query outside the half range
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
 // lanes' two smallest tile minima bounds the nprobe-th smallest element --, and only the tiles whose minimum passes the
 // threshold are read: ~nprobe + a few tiles of 128 bytes instead of the whole row (32 KB at 16 384 columns, 256 KB at 2^17).
 // Passing tiles are listed in LDS; 4 lanes then share a tile (16 halves each), 16 tiles per step.
+template <int MT>
 __global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Float16* __restrict__ dist, const float* __restrict__ tmin,
                                                                        int64_t nq, int nlist, int nprobe, const float* __restrict__ qn,
                                                                        const float* __restrict__ qn0, const unsigned char* __restrict__ flags,
@@ -360,12 +373,14 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Fl
     if (q >= nq) return;                        // whole wave; no workgroup barrier below
     const int ntile = nlist >> 6;
     const float* tm = tmin + q * ntile;
-    float m1 = FLT_MAX_F, m2 = FLT_MAX_F;
+    float mt[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) mt[i] = FLT_MAX_F;
     for (int t0 = 0; t0 < ntile; t0 += 64) {
         const int t = t0 + lane;
-        if (t < ntile) lane_top2(m1, m2, tm[t]);
+        if (t < ntile) lane_top<MT>(mt, tm[t]);
     }
-    const float cut_s = screen_cut(m1, m2, nprobe, lane);
+    const float cut_s = screen_cut<MT>(mt, nprobe, lane);
     bool finite;
     const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
     const bool undecided = !finite || flags[q];
@@ -470,6 +485,7 @@ __device__ __forceinline__ float exact_ip_batch(const float* __restrict__ Cn, in
 // centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's 64-byte piece (a lane reading
 // its own row would touch 64 cache lines per load instruction), the owner reads its row back component by component
 // (rows padded to 20 floats: 16-byte LDS accesses both ways); the next chunk's pieces are requested before the current one is used.
+template <int KPL>
 __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t* __restrict__ keep, const uint16_t* __restrict__ nkeep,
                                                                   int64_t nq, int nlist, int nprobe, float* __restrict__ cdis,
                                                                   int64_t* __restrict__ keys, const float* __restrict__ Q,
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
     for (int u = 0; u < kKeepCap / 64; u++) cand[wave][u * 64 + lane] = kc[u];
     qrow[wave][lane] = q0;
     qrow[wave][lane + 64] = q1;
-    WaveSelect<1> sel;
+    WaveSelect<KPL> sel;
     sel.init(nprobe, queue[wave], lane);
     __builtin_amdgcn_wave_barrier();
     if (!exact_row) {
@@ -524,11 +540,15 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
         if (kept_total && lane == 0) atomicAdd(kept_total, (unsigned long long)nlist);
     }
     sel.flush();
-    if (lane < nprobe) {
-        const u64 key = sel.best[0];
-        const bool miss = key == kMaxKey;
-        cdis[q * nprobe + lane] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
-        keys[q * nprobe + lane] = miss ? -1 : (int64_t)(uint32_t)key;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = r * 64 + lane;
+        if (e < nprobe) {
+            const u64 key = sel.best[r];
+            const bool miss = key == kMaxKey;
+            cdis[q * nprobe + e] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
+            keys[q * nprobe + e] = miss ? -1 : (int64_t)(uint32_t)key;
+        }
     }
 }
 
@@ -602,7 +622,8 @@ __global__ __launch_bounds__(256) void coarse_screen_nn_kernel(const float* __re
 }  // namespace
 
 bool coarse_screen_shape_ok(int nlist, int d, int nprobe) {
-    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= (1 << 20) && nprobe >= 2 && nprobe <= 64;
+    return d >= 4 && d <= 128 && d % 4 == 0 && nlist % 64 == 0 && nlist >= 256 && nlist <= (1 << 20) && nprobe >= 2 && nprobe <= 128 &&
+           nprobe * 2 <= nlist;      // (the cut pool needs nprobe distinct columns)
 }
 
 void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float scale, void* out_half, float* norms, float* norms_c,
@@ -652,18 +673,30 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     uint32_t* keep = reinterpret_cast<uint32_t*>(keep_ws);
     uint16_t* nkeep = reinterpret_cast<uint16_t*>(keep + (size_t)nq * kKeepCap);
     dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
-#define VLQ_SCR(NV) hipLaunchKernelGGL(coarse_screen_keep_kernel<NV>, sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, \
-                                       cmax0, c_sub, 1.f / sd, keep, nkeep, exact_rows)
-    if (nlist <= 1024) VLQ_SCR(4);
-    else if (nlist <= 2048) VLQ_SCR(8);
-    else if (nlist <= 4096) VLQ_SCR(16);
-    else if (nlist <= 8192) VLQ_SCR(32);
-    else
-        hipLaunchKernelGGL(coarse_screen_keep_tiled_kernel, sgrid, block, 0, s, ah, tmin, nq, nlist, nprobe, qn_c, qn, q_flags, cmax, cmax0,
-                           c_sub, 1.f / sd, keep, nkeep, exact_rows);
+#define VLQ_SCR(NV, MT) hipLaunchKernelGGL((coarse_screen_keep_kernel<NV, MT>), sgrid, block, 0, s, ah, nq, nlist, nprobe, qn_c, qn, q_flags, \
+                                           cmax, cmax0, c_sub, 1.f / sd, keep, nkeep, exact_rows)
+#define VLQ_SCRT(MT) hipLaunchKernelGGL(coarse_screen_keep_tiled_kernel<MT>, sgrid, block, 0, s, ah, tmin, nq, nlist, nprobe, qn_c, qn, q_flags, \
+                                        cmax, cmax0, c_sub, 1.f / sd, keep, nkeep, exact_rows)
+    // cut pool: the 2 (nprobe <= 64) or 4 (<= 128) smallest elements / tile minima of every lane
+    if (nprobe <= 64) {
+        if (nlist <= 1024) VLQ_SCR(4, 2);
+        else if (nlist <= 2048) VLQ_SCR(8, 2);
+        else if (nlist <= 4096) VLQ_SCR(16, 2);
+        else if (nlist <= 8192) VLQ_SCR(32, 2);
+        else VLQ_SCRT(2);
+        hipLaunchKernelGGL(coarse_screen_exact_kernel<1>, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
+                           kept_total);
+    } else {
+        if (nlist <= 1024) VLQ_SCR(4, 4);
+        else if (nlist <= 2048) VLQ_SCR(8, 4);
+        else if (nlist <= 4096) VLQ_SCR(16, 4);
+        else if (nlist <= 8192) VLQ_SCR(32, 4);
+        else VLQ_SCRT(4);
+        hipLaunchKernelGGL(coarse_screen_exact_kernel<2>, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
+                           kept_total);
+    }
 #undef VLQ_SCR
-    hipLaunchKernelGGL(coarse_screen_exact_kernel, sgrid, block, 0, s, keep, nkeep, nq, nlist, nprobe, cdis, keys, q, c, qn, cn, d,
-                       kept_total);
+#undef VLQ_SCRT
 }
 
 bool coarse_screen_nn_shape_ok(int nlist, int d) {
