@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
         const int c = line / a.nedge;
         if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
         __syncthreads();                         // previous line fully scanned
+        __builtin_amdgcn_s_setprio(2);           // table build + next line's loads first (see scan16.hip)
         if (c != cprev) {                        // new anchor: its row into registers, T23 into LDS
             const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)c * E);
 #pragma unroll
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 4 : 2) void line16_scan_kernel(Line
             const int w2 = min(w + 2, cnt - 1);
             mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
         const uint8_t* lp = a.lambdas + off;
@@ -630,6 +632,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 5 : 2) void line16h_scan_kernel(Lin
             cprev = c;
         }
         __syncthreads();                         // previous line fully scanned
+        __builtin_amdgcn_s_setprio(2);           // table build + next line's loads first (see scan16.hip)
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             H8 t4;
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(256, KPL <= 4 ? 5 : 2) void line16h_scan_kernel(Lin
             load_codes(mcur);
             mnext = mqw[12 * min(w + 2, cnt - 1) + fl];
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + off;
         const uint8_t* lp = a.lambdas + off;
@@ -783,6 +787,7 @@ __global__ __launch_bounds__(256) void lineS_scan_kernel(LineScanArgs a, int que
         const int c = line / a.nedge;
         if (t == 0) { cum[rank] = pos0; wmap[rank] = (uint16_t)w; }
         __syncthreads();                         // previous line fully scanned
+        __builtin_amdgcn_s_setprio(2);           // table build + next line's loads first (see scan16.hip)
         if (c != cprev) {                        // new anchor: its row into registers, T23 into LDS
             const float* src = a.term2 + (size_t)c * Eact;
 #pragma unroll
@@ -805,6 +810,7 @@ __global__ __launch_bounds__(256) void lineS_scan_kernel(LineScanArgs a, int que
             const int w2 = min(w + 2, cnt - 1);
             mb0 = mq[3 * w2]; mb1 = mq[3 * w2 + 1]; mb2 = mq[3 * w2 + 2];
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
             const uint32_t j = j0 + lane;
@@ -915,11 +921,13 @@ __global__ __launch_bounds__(256) void line_scan_kernel(LineScanArgs a, int lut_
         const float* t2c = a.term2 + (size_t)c * E;
         const float* t2s = a.term2 + (size_t)s * E;
         __syncthreads();                         // previous line fully scanned
+        __builtin_amdgcn_s_setprio(2);           // table build + next line's loads first (see scan16.hip)
         for (int e = t; e < E; e += 256) {
             const float vc = t2c[e];
             t23[e] = __fadd_rn(vc, __fmul_rn(-2.f, qt[e]));
             t4[e] = __fsub_rn(t2s[e], vc);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         const uint8_t* cp = a.codes + off * a.M;
         const uint8_t* lp = a.lambdas + off;

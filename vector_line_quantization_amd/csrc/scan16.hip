@@ -147,9 +147,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + n_off;
         float* L = lut + buf * E;
         if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
+        // the table build and the next list's first loads at raised wave priority: the workgroup's
+        // other waves wait at the barrier below for the slowest builder, whose stores and global
+        // loads otherwise queue behind the gathers of the CU's other workgroups (scan 0.665 ->
+        // 0.655 ms at the headline shape; levels 1..3 measure the same)
+        __builtin_amdgcn_s_setprio(2);
         build_lut16<NI>(L, t, t2r, m2t3);
         uint4 cc = c0, cd = c1;
         prefetch(i + 1);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (sel.dirty) {     // wave-uniform: publish this wave's k-th distance, then take the workgroup's minimum
             if (lane == 0) atomicMin(wg_thr, f32_to_ordered(sel.thr_own));

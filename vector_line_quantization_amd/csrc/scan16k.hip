@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
         const uint32_t pos0 = n_pos0;
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + n_off;
         if (i > 0 && !tripped) __syncthreads();                // (an empty list before: no trip barrier has said that everyone is done with the table)
+        __builtin_amdgcn_s_setprio(2);                         // as in scan16.hip: the barrier below waits for the slowest builder
         build_lut16<NI>(lut, t, t2r, m2t3);
         uint4 cc = c0;
         prefetch(i + 1);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         // trips of 256 consecutive codes; the trip count is the same for every thread
         for (uint32_t j0 = 0; j0 < len; j0 += NT) {
