@@ -723,11 +723,12 @@ def main():
                      "lut_bytes_separate": lut_bytes,
                      "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
                      # what actually bounds this kernel: one random 32-bit LDS gather per code byte.  Peak = the measured
-                     # gather rate of the LDS pipe (tools/micro/lds_gather.hip: 12.2 lanes per clock and CU at 16 waves per
-                     # CU, 2.4 GHz nominal, 256 CUs) -- reported beside the HBM fraction the contract asks for
+                     # gather rate of the LDS pipe for uniformly random byte indices (tools/micro/lds_gather.hip: 9.98 lanes
+                     # per clock and CU at 16 waves per CU, 2.4 GHz nominal, 256 CUs; bank arithmetic: 64 / (2 x 3.15)) --
+                     # reported beside the HBM fraction the contract asks for
                      "lds_gather": {"achieved_per_clock_cu": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 if scan_ms > 0 else 0.0,
-                                    "peak_per_clock_cu": 12.2,
-                                    "frac": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 / 12.2 if scan_ms > 0 else 0.0}},
+                                    "peak_per_clock_cu": 9.98,
+                                    "frac": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 / 9.98 if scan_ms > 0 else 0.0}},
         "stage_ms": {"coarse": prof_all["coarse_ms"] / 5, "tables": prof_all["tables_ms"] / 5,
                      "scan": prof_all["scan_ms"] / 5, "note": "from 5 extra untimed steps with every stage instrumented"},
     }

@@ -12,14 +12,15 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ g
     const float* gt = gtab + (size_t)(blockIdx.x & 1023) * (NG ? NG : 1) * 256;
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
     float acc = 0.f;
+    auto mix = [](uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; };
     for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            x = x * 1664525u + 1013904223u;
-            const uint32_t c = x >> 8;
+            x += 0x9E3779B9u;
+            const uint32_t c = mix(x);            // four uniform, independent index bytes (see lds_gather.hip on why not LCG bytes)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t j = ((c >> (8 * (m % 3))) + 37u * m) & 255u;
+                const uint32_t j = (c >> (8 * m)) & 255u;
                 const int s = u * 4 + m;
                 if (s < NG) acc += gt[s * 256 + j];
                 else acc += lds[s * 256 + j];
