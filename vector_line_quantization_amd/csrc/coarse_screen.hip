@@ -252,7 +252,7 @@ __device__ __forceinline__ float screen_cut(const float (&m)[MT], int nprobe, in
     u64 row = p[0];
 #pragma unroll
     for (int i = 1; i < MT; i++) row = (e >> 6) == i ? p[i] : row;
-    return ordered_to_f32((uint32_t)(shfl_u64(row, e & 63) >> 32));
+    return ordered_to_f32((uint32_t)(bcast_u64(row, e & 63) >> 32));
 }
 
 // smallest of a float over the wave, as bits (DPP inside rows of 16, readlane across; NaN inputs lose to numbers: fminf)

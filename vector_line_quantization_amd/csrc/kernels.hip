@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256) void coarse_select_reg_kernel(const float* __r
     }
     // cut = nprobe-th smallest lane minimum (lanes whose minimum is FLT_MAX hold nothing admissible)
     const u64 sorted = wave_sort64(((u64)f32_to_ordered(mn) << 32) | (uint32_t)lane, lane);
-    const float cut = ordered_to_f32((uint32_t)(shfl_u64(sorted, nprobe - 1) >> 32));
+    const float cut = ordered_to_f32((uint32_t)(bcast_u64(sorted, nprobe - 1) >> 32));
     auto pass = [&](float x) { return x <= cut && x < FLT_MAX_F; };
     int cnt = 0;
 #pragma unroll

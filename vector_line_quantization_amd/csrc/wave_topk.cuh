@@ -38,23 +38,50 @@ __device__ __forceinline__ u64 make_key(float dis, uint32_t pos) {
     return ((u64)f32_to_ordered(dis) << 32) | pos;
 }
 
-// value of lane (lane ^ stride); stride is a compile-time constant after unrolling.  Strides 1, 2
-// and 8 are DPP moves (VALU, no LDS round trip), 4 and 16 the LDS crossbar without an address
-// register (ds_swizzle bit mode), 32 a ds_bpermute.
+// value of lane (lane ^ stride); stride is a compile-time constant after unrolling.  Every stride is a VALU
+// move -- no trip through the LDS crossbar, whose queue is where the list scans' gathers wait: a ds_swizzle or
+// ds_bpermute issued by a selection under a saturated LDS pipe returns after hundreds of cycles.  1, 2: quad_perm;
+// 4: two bank-masked row shifts; 8: row_ror:8; 16 / 32: gfx950's v_permlane16_swap / v_permlane32_swap (with
+// both operands = v the swap leaves lane^16 resp. lane^32 in one of the two results, by lane half).
+__device__ __forceinline__ uint32_t wave_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int stride) {
     switch (stride) {
         case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
         case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
         case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
-        case 4: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (4 << 10));           // and 0x1f, xor 4
-        case 16: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (16 << 10));
-        default: return (uint32_t)__shfl_xor((int)v, stride, 64);
+        case 4: {   // lanes 0-3, 8-11 of a row take lane+4 (row_shl:4, banks 0 and 2), the others lane-4 (row_shr:4, banks 1 and 3)
+            const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+            return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+        }
+        case 16: {  // rows 1, 3 of r[0] <-> rows 0, 2 of r[1]
+            const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+            return (wave_lane_id() & 16u) ? r[0] : r[1];
+        }
+        default: {  // 32: upper half of r[0] <-> lower half of r[1]
+            const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            return (wave_lane_id() & 32u) ? r[0] : r[1];
+        }
     }
 }
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = lane_xor_u32(lo, mask);
     hi = lane_xor_u32(hi, mask);
+    return ((u64)hi << 32) | lo;
+}
+// value of lane 63 - lane: row_mirror inside the rows of 16, then the rows exchanged
+__device__ __forceinline__ u64 lane_reverse_u64(u64 v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x140, 0xF, 0xF, true);
+    hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x140, 0xF, 0xF, true);
+    lo = lane_xor_u32(lane_xor_u32(lo, 16), 32);
+    hi = lane_xor_u32(lane_xor_u32(hi, 16), 32);
+    return ((u64)hi << 32) | lo;
+}
+// value of lane `src`, src wave-uniform (v_readlane)
+__device__ __forceinline__ u64 bcast_u64(u64 v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((u64)hi << 32) | lo;
 }
 // compare-exchange results with one 64-bit compare: the smaller (want_min) or larger of (a, b)
@@ -167,7 +194,7 @@ __device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, Pending<QR>
     // pending reversed (element e -> N-1-e) against the tail of the best list: bitonic split
 #pragma unroll
     for (int r = 0; r < QR; r++) {
-        const u64 rev = shfl_u64(p[QR - 1 - r], 63 - lane);
+        const u64 rev = lane_reverse_u64(p[QR - 1 - r]);
         b.v[KPL - QR + r] = umin64(b.v[KPL - QR + r], rev);
     }
     wave_bitonic_merge<KPL>(b.v, lane);
@@ -176,7 +203,7 @@ __device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, Pending<QR>
     u64 row = b.v[0];
 #pragma unroll
     for (int r = 1; r < KPL; r++) row = (r == kr) ? b.v[r] : row;
-    const u64 kth = shfl_u64(row, kl);
+    const u64 kth = bcast_u64(row, kl);
     // a missing k-th (kMaxKey) keeps the threshold at FLT_MAX
     b.kth = (kth == kMaxKey) ? 3.402823466e+38f : ordered_to_f32((uint32_t)(kth >> 32));
     return b;
