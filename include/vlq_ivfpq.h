@@ -198,7 +198,8 @@ int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset);
  * reset, on the index's stream: ms[0]=coarse (norms+GEMM+select), ms[1]=query
  * tables, ms[2]=list scan (+top-k), calls = number of timed scan launches.
  * enable: 0 = off, 1 = every stage (six event records per call), 2 = the scan kernel only
- * (two event records: what a benchmark's timed region can afford). */
+ * (two event records per call), 3 = the scan kernel of every 4th call, starting with the
+ * next one (an event record is a queue barrier: it costs the call more than it measures). */
 int vlq_ivfpq_profile(vlq_ivfpq_t h, int enable);
 int vlq_ivfpq_profile_read(vlq_ivfpq_t h, double ms[3], int64_t* calls, int reset);
 

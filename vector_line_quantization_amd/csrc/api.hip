@@ -47,6 +47,7 @@ struct StageTimer {
     vlq_ivfpq_t h; int stage; hipEvent_t a = nullptr, b = nullptr;
     StageTimer(vlq_ivfpq_t h_, int stage_) : h(h_), stage(stage_) {
         if (!h->prof || (h->prof_scan_only && stage != 2)) return;
+        if (h->prof_every > 1 && stage == 2 && (h->prof_seq++ % (uint64_t)h->prof_every) != 0) return;
         a = get_event(h); b = get_event(h);
         if (a) (void)hipEventRecord(a, h->stream);
     }
@@ -1143,7 +1144,9 @@ int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
 int vlq_ivfpq_profile(vlq_ivfpq_t h, int enable) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     h->prof = enable != 0;
-    h->prof_scan_only = enable == 2;
+    h->prof_scan_only = enable == 2 || enable == 3;
+    h->prof_every = enable == 3 ? 4 : 1;
+    h->prof_seq = 0;
     return VLQ_OK;
 }
 

@@ -146,6 +146,8 @@ struct vlq_ivfpq_s {
 
     // profiling
     bool prof = false, prof_scan_only = false;
+    int prof_every = 1;              // scan-only timing of every prof_every-th search call (profile mode 3: every 4th)
+    uint64_t prof_seq = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     struct Pending { hipEvent_t a, b; int stage; };
     std::vector<Pending> pending;
