@@ -422,11 +422,12 @@ TIMED_PROFILE = 3
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 100 timed steps after 20 warm-up steps (0.1 s of GPU time).  The first ~20 steps after the set-up's host
-    # round trips run ~8 % slower (20 steps after 3: 0.81-0.82 ms per step, 100 after 20: 0.76; the scan kernel itself
-    # 0.70 against 0.65 ms), so a 20-step region measures the ramp, not the rate
+    # defaults: 100 timed steps after 40 warm-up steps (0.11 s of GPU time).  After any idle period (the set-up's host round
+    # trips) the GPU needs ~30 steps = 25 ms to reach its clocks: per-step times 0.89, 0.83, 0.79, 0.76, 0.76 ... for
+    # consecutive groups of ten (tools/clock_ramp.py), the scan kernel itself 0.70 -> 0.65 ms.  A 20-step region after 3
+    # warm-up steps (the round-1/2 default) measured that ramp, 0.81-0.82 ms per step, not the rate
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nb", type=int, default=1000000)
     ap.add_argument("--nt", type=int, default=100000)
