@@ -362,6 +362,25 @@ def test_device_resident_buffers():
     assert np.array_equal(I.cpu().numpy(), Io)
 
 
+def test_stage_timer_modes():
+    """vlq_ivfpq_profile: 1 = every stage of every call, 2 = the scan launch of every call, 3 = the scan launch of every
+    4th call starting with the next one (what bench.py's timed region uses); results do not depend on the mode."""
+    case = Case("c1_small")
+    g = gpu_index(case)
+    D0, I0 = g.search(case.xq, case.nprobe, case.k)
+    for mode, want_calls, stages in ((1, 8, True), (2, 8, False), (3, 2, False), (0, 0, False)):
+        g.profile(mode)
+        g.profile_read(reset=True)
+        for _ in range(8):
+            D, I = g.search(case.xq, case.nprobe, case.k)
+            assert np.array_equal(bits(D), bits(D0)) and np.array_equal(I, I0)
+        p = g.profile_read(reset=True)
+        assert p["scan_calls"] == want_calls, (mode, p)
+        assert (p["scan_ms"] > 0) == (want_calls > 0)
+        assert (p["coarse_ms"] > 0) == stages
+    g.profile(False)
+
+
 @pytest.mark.parametrize("nq", [100, 4096, 5000])
 def test_host_buffers_pageable_and_page_locked(nq):
     """The reference drivers' calling convention: x / D / I in host memory.  4 096 queries and more: the batch is copied
