@@ -225,7 +225,8 @@ class GpuIVFPQ:
         return nq.value, ncode.value
 
     def profile(self, enable=True):
-        """0 / False: off; 1 / True: every stage; 2: the scan kernel only (two event records per call)"""
+        """0 / False: off; 1 / True: every stage; 2: the scan kernel only (two event records per call);
+        3: the scan kernel of every 4th call, starting with the next one"""
         check(lib().vlq_ivfpq_profile(self._h, C.c_int(int(enable))))
 
     def profile_read(self, reset=True):
