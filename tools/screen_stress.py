@@ -2,7 +2,7 @@
 """Randomised check of the coarse stage's float16 screen against the matrix path of the same library (the switch is speed
 only: vlq_ivfpq_set_coarse_screen): random shapes, scales, offsets, cluster structure, quantised coordinates (ties),
 duplicated centroids, queries on centroids; keys and distances must be bit-identical.  Also nprobe = 1 (the nearest-
-centroid screen behind add / encode).   python tools/screen_stress.py [cases] [seed]"""
+centroid screen behind add / encode).   python tools/screen_stress.py [cases] [seed]   (IMI=1: the two halves of a multi-index instead)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -41,6 +41,31 @@ for case in range(ncase):
     else:
         cent = 3e3 * rng.standard_normal((nlist, d)); xq = 3e3 * rng.standard_normal((nq, d))
     cent = cent.astype(np.float32); xq = xq.astype(np.float32)
+    if os.environ.get("IMI") == "1" and d >= 32 and d % 8 == 0:
+        # the two halves of an inverted multi-index: sub-centroids = the halves of the first kc centroids, walk of nprobe cells
+        nbits = int(rng.choice([8, 9, 10, 12])); kc = 1 << nbits; dc = d // 2
+        src = np.concatenate([cent] * (kc // nlist + 1))[:kc] if nlist < kc else cent[:kc]
+        imi = np.ascontiguousarray(np.stack([src[:, :dc], src[:, dc:]]))
+        if nlist < kc:
+            imi = imi + (1e-3 * rng.standard_normal(imi.shape)).astype(np.float32)
+        imi[0, 7:20] = imi[0, 5]
+        nprobe = min(nprobe, 64)
+        g = vlq.GpuIVFPQ(d, kc * kc, 4, 8)
+        g.set_imi_centroids(nbits, imi.astype(np.float32))
+        g.set_pq_centroids(rng.random((4, 256, d // 4)).astype(np.float32))
+        g.set_coarse_screen(1)
+        cd1, k1 = g.coarse_search(xq, nprobe)
+        st = g.coarse_screen_state()
+        g.set_coarse_screen(0)
+        cd0, k0 = g.coarse_search(xq, nprobe)
+        ok = np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(k1, k0)
+        if not ok:
+            bad += 1
+            print("MISMATCH imi case %d: %s d=%d nbits=%d nprobe=%d nq=%d state=%s" % (case, kind, d, nbits, nprobe, nq, st), flush=True)
+        elif case % 10 == 0:
+            print("imi case %d ok: %s d=%d nbits=%d nprobe=%d nq=%d screen state %s (%.0f s)" % (case, kind, d, nbits, nprobe, nq, st, time.time() - t0), flush=True)
+        del g
+        continue
     cent[nlist // 3:nlist // 3 + 20] = cent[1]                        # duplicated centroids
     xq[:32] = cent[rng.integers(0, nlist, 32)]                       # queries on centroids
     M = 4
