@@ -241,6 +241,22 @@ __device__ __forceinline__ void adc16_pipeline(const uint4 (&c)[N], float dis0, 
 #undef VLQ_ISSUE
 }
 
+// one chunk in two half blocks: the 8 adds of the first half run while the second half's reads are in flight
+template <int BUF>
+__device__ __forceinline__ float adc16_halves(const uint4 cc, float dis, uint32_t two) {
+    float lo[8], hi[8];
+    if (BUF == 0) { { float (&v)[8] = lo; VLQ_G8LO_NW(0, cc.x, cc.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(0, cc.z, cc.w); } }
+    else { { float (&v)[8] = lo; VLQ_G8LO_NW(16384, cc.x, cc.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(16384, cc.z, cc.w); } }
+    VLQ_WAIT8(8, lo);
+#pragma unroll
+    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, lo[m]);
+    asm volatile("" : "+v"(dis));
+    VLQ_WAIT8(0, hi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hi[m]);
+    return dis;
+}
+
 template <int BUF>
 __device__ __forceinline__ float adc16_fixed(const uint4 cc, float dis, uint32_t two) {
     float v[16];
