@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
             for (; j0 < len; j0 += NT) {
                 const uint32_t j = j0 + lane;
                 const uint4 cn = cp[min(j + NT, len - 1)];
-                const float dis = PIPE ? adc16_halves<B>(cc, dis0, two) : adc16_fixed<B>(cc, dis0, two);
+                const float dis = adc16_halves<B>(cc, dis0, two);
                 sel.offer(dis, pos0 + j, j < len);
                 cc = cn;
             }

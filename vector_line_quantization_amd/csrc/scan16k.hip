@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
         for (uint32_t j0 = 0; j0 < len; j0 += NT) {
             const uint32_t j = j0 + t;
             const uint4 cn = cp[min(j + NT, len - 1)];
-            const float dis = adc16_fixed<0>(cc, dis0, two);
+            const float dis = adc16_halves<0>(cc, dis0, two);
             const bool pred = j < len && dis <= thr && dis < 3.402823466e+38f;
             const u64 mask = __ballot(pred);
             const int cnt = __popcll(mask);
