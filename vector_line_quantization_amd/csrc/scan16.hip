@@ -559,6 +559,8 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     // LUT buffer with 6 workgroups per CU 0.78 ms, two probes of lookahead 0.82 ms, two
     // queries per workgroup sharing term2 rows 0.93 ms -- against 0.78-0.82 ms for this
     // configuration (4 waves, double-buffered LUT, one probe of lookahead).
+    // (r03, against 0.649 ms: single LUT buffer without the pair loop = 99 VGPRs = 5 workgroups per CU 0.682 ms, single
+    // buffer with the pair loop at 4 per CU 0.668 ms.)
     const int nw = 4;
     size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
