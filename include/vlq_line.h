@@ -88,14 +88,22 @@ int vlq_line_profile_read(vlq_line_t h, double* scan_ms, int64_t* launches, int 
 int vlq_line_set_float16_tables(vlq_line_t h, int enable);
 
 /* Where the 16-byte scan takes a line's term-2 rows from (speed / memory only: the results are bit-identical):
- *   0, 1 = rows read from the stored [nlist][M][ksub] table, as the reference's kernel reads them
- *       (impl/PQScanMultiPassPrecomputed.cu:54-75,313-334); 0 = "automatic" resolves to this, the faster one
+ *   0, 3 = the query-independent half of a code's distance, la * sum_m term4[m][code_m] (impl/PQScanMultiPassPrecomputed.cu:
+ *       783-811; term4 = term2[s] - term2[c] depends on the line a code is stored on, not on the query), is computed once
+ *       per database state with the scan's own operations and read back as 4 bytes per stored code (line16c.hip; M = 16 x 8
+ *       bit): no far-end row, one table per anchor centroid, half the look-ups.  0 = "automatic" resolves to this.
+ *   1 = rows read from the stored table per line, as the reference's kernel reads them
  *   2 = rows rebuilt in registers from the far-end centroid and the PQ codebook (line16r.hip; M = 16 x 8 bit,
  *       dsub in {4, 6, 8}, k <= 256, fp32 tables -- other shapes keep the stored rows): no term-2 table in HBM
  *       at all (1 GiB less at 65 536 centroids) and a quarter of the scan's HBM traffic (11 against 45 GB per
  *       2000 queries at the reference driver's geometry), paid for with 2.7x the VALU work: 8.8 against 7.1 ms
  *       there.  For memory-constrained deployments; not the default. */
 int vlq_line_set_row_mode(vlq_line_t h, int mode);
+/* Workgroups per query of the scan with stored per-code constants (row mode 0 / 3): a query's kept codes are cut
+ * into `parts` equal ranges scanned by separate workgroups whose candidates a merge kernel joins under the total
+ * order (distance, scan position) -- results do not depend on it.  0 = automatic: the count that fills the chip's
+ * last round best (small batches, e.g. the per-GPU slice of a sharded batch, get several).  1..64. */
+int vlq_line_set_scan_parts(vlq_line_t h, int parts);
 
 #ifdef __cplusplus
 }

@@ -100,10 +100,11 @@ def test_line_cap_1024_codes():
     assert g.stats() == v.last_ncode < xq.shape[0] * 6000
 
 
-@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("rows", [1, 2, 3])
 def test_m16_8bit_d128_shape(rows):
     """The 16-byte-code shape of the reference's deep1b16 / sift1b16 drivers; term-2 rows read from the
-    stored table (line16_scan_kernel) and rebuilt in registers (line16r_scan_kernel, dsub = 8)."""
+    stored table (line16_scan_kernel), rebuilt in registers (line16r_scan_kernel, dsub = 8), and the scan with
+    the stored per-code constants (line16c_scan_kernel, rows = 3 = what 0 / automatic resolves to)."""
     v, xb, xq = make_vlq(seed=5, d=128, nlist=32, M=16, nbits=8, nedge=8, nlambda=64, nb=4000)
     g = gpu_from_oracle(v)
     g.set_row_mode(rows)
@@ -118,14 +119,15 @@ def world16():
     return make_vlq(seed=11, d=96, nlist=200, M=16, nbits=8, nedge=8, nlambda=256, nb=20000)
 
 
-@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("rows", [1, 2, 3])
 @pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (16, 128, 128), (64, 300, 300), (8, 64, 1),
                                          (128, 1024, 128), (200, 1024, 1000), (3, 5, 64), (64, 1024, 256)])
 def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k, rows):
     """line16_scan_kernel (anchor-grouped lines, compact line records, two-table gathers; rows = 1) and
     line16r_scan_kernel (term-2 rows rebuilt from the centroid and the codebook, interleaved double-buffered
-    table; rows = 2, k <= 256 -- larger selections fall back to the stored rows) against the oracle over the
-    selection sizes of the wave select (w1 -> 1/4/16 keys per lane, k likewise)."""
+    table; rows = 2, k <= 256 -- larger selections fall back to the stored rows) and line16c_scan_kernel (one table
+    per anchor, the query-independent la * sum(term 4) read as a stored per-code constant; rows = 3) against the
+    oracle over the selection sizes of the wave select (w1 -> 1/4/16 keys per lane, k likewise)."""
     v, _, xq = world16
     g = gpu_from_oracle(v)
     g.set_row_mode(rows)
@@ -136,7 +138,23 @@ def test_m16_scan_kernel_bit_exact(world16, nprobe, w1, k, rows):
     assert g.stats() == v.last_ncode
 
 
-@pytest.mark.parametrize("rows", [1, 2])
+@pytest.mark.parametrize("parts", [2, 3, 7, 64])
+@pytest.mark.parametrize("fp16", [False, True])
+@pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (64, 300, 300), (128, 1024, 128), (3, 5, 64), (200, 1024, 1000)])
+def test_m16_scan_in_parts_is_the_same_scan(world16, nprobe, w1, k, fp16, parts):
+    """line16c_scan_kernel with a query's kept codes cut into ranges scanned by separate workgroups (cuts fall inside
+    lines and inside anchor groups; with 64 parts some are empty) + line16c_merge_kernel: the same rows, bit for bit."""
+    v, _, xq = world16
+    g = gpu_from_oracle(v)
+    g.set_float16_tables(fp16)
+    g.set_scan_parts(parts)
+    D, I = g.search(xq, nprobe, w1, k)
+    Do, Io = v.search(xq, nprobe, w1, k, fp16=fp16)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+    assert g.stats() == v.last_ncode
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3])
 def test_m16_line_cap_and_big_batch(rows):
     v, xb, xq = make_vlq(seed=13, d=128, nlist=6, M=16, nbits=8, nedge=2, nlambda=32, nb=9000)
     assert np.diff(v.line_off).max() > 1024
@@ -179,6 +197,8 @@ def test_random_vlq_configuration(seed):
     g = gpu_from_oracle(v, with_lists=False)
     cut = nb // 3
     g.add(xb[:cut])
+    if M == 16 and seed % 2 == 0:      # a search between the adds: the per-code constants must be rebuilt after the second
+        g.search(xq[:4], 4, 7, 10)
     g.add(xb[cut:])
     assert g.ntotal == nb
     for line in range(nlist * nedge):
@@ -192,21 +212,24 @@ def test_random_vlq_configuration(seed):
     Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True)
     assert np.array_equal(lines, lo)
     assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
-    if M == 16:        # term-2 rows rebuilt in the kernel (dsub 4 / 6 / 8, k <= 256; other shapes keep the stored rows)
-        g.set_row_mode(2)
-        D1, I1 = g.search(xq, nprobe, w1, k)
-        assert np.array_equal(bits(D1), bits(Do)) and np.array_equal(I1, Io)
+    if M == 16:        # the default above is the per-code-constant scan; rows read from the stored table (1) and rebuilt
+        for rows in (1, 2):   # in the kernel (2: dsub 4 / 6 / 8, k <= 256; other shapes keep the stored rows) must agree
+            g.set_row_mode(rows)
+            D1, I1 = g.search(xq, nprobe, w1, k)
+            assert np.array_equal(bits(D1), bits(Do)) and np.array_equal(I1, Io)
 
 
 # ---------------------------------------------------------------------------------------------
 # float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [1, 3])
 @pytest.mark.parametrize("nprobe,w1,k", [(8, 32, 10), (16, 128, 128), (64, 300, 300), (128, 1024, 128), (200, 1024, 1000)])
-def test_fp16_tables_bit_exact_vs_fp16_oracle(world16, nprobe, w1, k):
+def test_fp16_tables_bit_exact_vs_fp16_oracle(world16, nprobe, w1, k, rows):
     """half(term 2), half(term 3), half add / subtract for the two tables, float accumulation: the
     device must reproduce the oracle's float16 mode bit for bit (same order, same ties)."""
     v, _, xq = world16
     g = gpu_from_oracle(v)
+    g.set_row_mode(rows)              # 1: line16h_scan_kernel; 3: line16c_scan_kernel with the half-table constants
     g.set_float16_tables(True)
     D, I, lines = g.search(xq, nprobe, w1, k, return_lines=True)
     Do, Io, lo = v.search(xq, nprobe, w1, k, return_lines=True, fp16=True)

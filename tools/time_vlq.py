@@ -59,6 +59,7 @@ pick = torch.randint(0, nlist, (nq,), device="cuda", generator=gen)
 xq = (torch.from_numpy(cent).cuda()[pick] + 0.08 * torch.randn((nq, d), device="cuda", generator=gen)).contiguous()
 nself = min(nq, first.shape[0]) // 2
 xq[:nself] = first[:nself]                              # half the batch: stored vectors
+if E("PARTS", 0): g.set_scan_parts(E("PARTS", 0))     # workgroups per query of the default scan (0 = automatic)
 if E("ROWS", 0): g.set_row_mode(E("ROWS", 0))            # 1: term-2 rows from the stored table, 2: rebuilt in the kernel
 fp16 = bool(E("FP16", 0))
 if fp16 or (M == 16 and nbits == 8): g.set_float16_tables(fp16)
@@ -69,11 +70,16 @@ for _ in range(2):
     g.search(xq, nprobe, w1, k, D=D, I=I)
 torch.cuda.synchronize()
 g.stats(reset=True)
+g.profile(True)
+g.profile_read(reset=True)
 t0 = time.time()
 for _ in range(reps):
     g.search(xq, nprobe, w1, k, D=D, I=I)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
+scan_ms, launches = g.profile_read(reset=True)
+g.profile(False)
+print("scan kernel: %.3f ms per launch (%d launches, HIP events on the index's stream)" % (scan_ms / max(launches, 1), launches))
 ncode = g.stats() / reps
 print("search: %.3f ms per %d queries = %.0f QPS; ncode/query=%.0f -> %.0f GB/s (code + lambda bytes)" % (
     dt * 1e3, nq, nq / dt, ncode / nq, ncode * (M + 1) / dt / 1e9))

@@ -20,7 +20,7 @@ SYMBOLS = [
     "vlq_ivfpq_get_precomputed_table", "vlq_ivfpq_stats", "vlq_ivfpq_profile",
     "vlq_ivfpq_profile_read", "vlq_merge_topk",
     # include/vlq_line.h
-    "vlq_line_set_float16_tables", "vlq_line_set_row_mode", "vlq_line_create", "vlq_line_destroy", "vlq_line_set_stream", "vlq_line_set_coarse_centroids",
+    "vlq_line_set_float16_tables", "vlq_line_set_row_mode", "vlq_line_set_scan_parts", "vlq_line_create", "vlq_line_destroy", "vlq_line_set_stream", "vlq_line_set_coarse_centroids",
     "vlq_line_set_pq_centroids", "vlq_line_set_lambda_codebook", "vlq_line_set_graph",
     "vlq_line_build_graph", "vlq_line_assign", "vlq_line_residuals", "vlq_line_encode", "vlq_line_add",
     "vlq_line_set_lists", "vlq_line_ntotal", "vlq_line_list_length", "vlq_line_get_list",

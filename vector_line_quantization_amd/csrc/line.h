@@ -24,7 +24,8 @@ struct LineMeta {
     uint32_t pos0;    // scan position of the line's first code: lines in the order the line select emits
                       // them (ascending key, BroadcastSum.cu:538-553), codes in list order
     int32_t rank;     // index of the line among the query's non-empty kept lines in that order
-    int32_t pad0, pad1;
+    int32_t anchor;   // c = line / nedge
+    int32_t pad1;
 };
 static_assert(sizeof(LineMeta) == 48, "LineMeta is read as three 16-byte words");
 
@@ -56,6 +57,11 @@ struct LineScanArgs {
     const int32_t* sel_line;     // [nq][w1]
     const float* sel_b2;         // [nq][w1]
     const float* sel_g;          // [nq][w1]
+    // per-code constants la * sum_m term4[m][code_m] (line16c.hip), in the precision of the tables in use
+    const float* pconst = nullptr;        // [capacity]
+    int nprobe = 0;                       // anchors per query (sizes the scan's group tables; 0: w1)
+    unsigned long long* part_keys = nullptr;   // [nq][nparts][k] (distance, scan position) keys of a query's parts
+    int nparts = 1;                       // workgroups per query (line16c_parts)
     const LineMeta* sel_meta = nullptr;   // [nq][w1] compact records (16-byte scan)
     const int32_t* sel_cnt = nullptr;     // [nq]
     float* D;
@@ -69,6 +75,16 @@ void launch_line_scan(const LineScanArgs& a, hipStream_t s);
 // launch_line_scan, bit for bit
 bool line16r_supports(const LineScanArgs& a, int dsub);
 void launch_line16r_scan(const LineScanArgs& a, int dsub, hipStream_t s);
+// per-code constants of the stored codes (line16c.hip): out[i] = la_i * sum_m (term2[s][m][c_m] - term2[c][m][c_m]) for
+// every code of every line, with the scan kernels' operations; term2h != nullptr: the float16 tables' form
+void launch_line_consts(const uint8_t* codes, const uint8_t* lambdas, const int64_t* line_off, const int64_t* line_len,
+                        const int32_t* edge_info, const float* term2, const uint16_t* term2h, const float* lambda_info,
+                        int nedge, int M, int ksub, int64_t nlines, float* out, hipStream_t s);
+// 16-byte codes with the stored constants: one table per anchor centroid, no far-end rows; same results as
+// launch_line_scan, bit for bit
+bool line16c_supports(const LineScanArgs& a);
+int line16c_parts(int64_t nq, int k, int max_parts);
+void launch_line16c_scan(const LineScanArgs& a, hipStream_t s);
 // out[i] = half(scale * in[i]) (round to nearest even); scale = 1 (term 2) or -2 (term 3, IVFPQ.cu:1409-1442)
 void launch_to_half(const float* in, int64_t n, float scale, uint16_t* out, hipStream_t s);
 

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void line_select_kernel(
         m.g = __fsub_rn(row[m.s], m.b2);
         m.pos0 = (uint32_t)k64 & ((1u << 30) - 1u);
         m.rank = (int32_t)((k64 >> 30) & 1023u);
-        m.pad0 = m.pad1 = 0;
+        m.anchor = (int32_t)c;
+        m.pad1 = 0;
         sel_meta[q * w1 + w] = m;
     }
     if (lane == 0) sel_cnt[q] = (int32_t)run_cnt;

@@ -20,8 +20,13 @@ struct vlq_line_s {
     std::vector<hipEvent_t> prof_pool;
     double prof_ms = 0;
     int64_t prof_calls = 0;
+    int scan_parts = 0;                  // vlq_line_set_scan_parts: workgroups per query of the line16c scan, 0 = automatic
     int row_mode = 0;                    // vlq_line_set_row_mode: 0 auto, 1 stored term-2 rows, 2 rebuilt rows
     DevBuf term2h, ws_qtabh;
+    // per-code constants of the stored codes (line16c.hip), one array per table precision; rebuilt lazily after anything
+    // they depend on changed (codes / lambda bytes / line layout, term 2 = coarse + PQ centroids, graph, lambda codebook)
+    DevBuf pconst, pconsth, ws_part_keys;
+    bool pconst_valid = false, pconsth_valid = false;
     std::vector<int64_t> h_line_off, h_line_len;
     bool h_lines_stale = false;
     AppendWs ws_append;
@@ -82,6 +87,24 @@ int encode_dev(vlq_line_t h, int64_t n, const float* xd) {
     return VLQ_OK;
 }
 
+// la * sum(term 4) of every stored code, in the precision of the tables the next scan uses
+int ensure_consts(vlq_line_t h, bool fp16) {
+    vlq_ivfpq_t b = h->base;
+    bool& valid = fp16 ? h->pconsth_valid : h->pconst_valid;
+    if (valid) return VLQ_OK;
+    DevBuf& buf = fp16 ? h->pconsth : h->pconst;
+    TRY(buf.reserve(h->codes.cap / (size_t)b->M * 4 + 16));      // one float per code slot of the current layout
+    vlq::launch_line_consts(h->codes.as<uint8_t>(), h->lambdas.as<uint8_t>(), h->line_off.as<int64_t>(),
+                            h->line_len.as<int64_t>(), h->edge_info.as<int32_t>(), b->term2.as<float>(),
+                            fp16 ? h->term2h.as<uint16_t>() : nullptr, h->lambda_info.as<float>(), h->nedge, b->M, b->ksub,
+                            h->nlines, buf.as<float>(), b->stream);
+    HIP_TRY(hipGetLastError());
+    valid = true;
+    return VLQ_OK;
+}
+
+void drop_consts(vlq_line_t h) { h->pconst_valid = h->pconsth_valid = false; }
+
 }  // namespace
 
 static vlq::ListStore line_store(vlq_line_t h) {
@@ -110,14 +133,14 @@ int vlq_line_create(vlq_line_t* out, int device, int d, int nlist, int M, int nb
     h->h_lines_stale = true;    // host copies are filled on first use
     rc = h->line_off.reserve(((size_t)h->nlines + 1) * 8);
     if (rc == VLQ_OK) rc = h->line_len.reserve((size_t)h->nlines * 8);
-    if (rc == VLQ_OK) rc = h->stats.reserve(16);
+    if (rc == VLQ_OK) rc = h->stats.reserve(64);
     if (rc == VLQ_OK) rc = h->codes.reserve(16);
     if (rc == VLQ_OK) rc = h->lambdas.reserve(16);
     if (rc == VLQ_OK) rc = h->ids.reserve(16);
     if (rc != VLQ_OK) { vlq_line_destroy(h); return rc; }
     (void)hipMemsetAsync(h->line_off.p, 0, ((size_t)h->nlines + 1) * 8, h->base->stream);
     (void)hipMemsetAsync(h->line_len.p, 0, (size_t)h->nlines * 8, h->base->stream);
-    (void)hipMemsetAsync(h->stats.p, 0, 16, h->base->stream);
+    (void)hipMemsetAsync(h->stats.p, 0, 64, h->base->stream);
     (void)hipStreamSynchronize(h->base->stream);
     *out = h;
     return VLQ_OK;
@@ -130,7 +153,7 @@ void vlq_line_destroy(vlq_line_t h) {
                       &h->line_off, &h->line_len, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_near, &h->ws_line, &h->ws_lamf, &h->ws_lamb, &h->ws_res,
                       &h->ws_codes, &h->ws_sel_line, &h->ws_sel_b2, &h->ws_sel_g, &h->ws_sel_meta, &h->ws_sel_cnt, &h->ws_x, &h->ws_D,
-                      &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats, &h->term2h, &h->ws_qtabh};
+                      &h->ws_I, &h->ws_keys, &h->ws_cdis, &h->stats, &h->term2h, &h->ws_qtabh, &h->pconst, &h->pconsth, &h->ws_part_keys};
     for (auto b : bufs) b->release();
     for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
@@ -145,8 +168,15 @@ int vlq_line_set_stream(vlq_line_t h, void* s) {
 
 int vlq_line_set_row_mode(vlq_line_t h, int mode) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 2) return fail(VLQ_ERR_INVALID, "row mode %d outside 0..2", mode);
+    if (mode < 0 || mode > 3) return fail(VLQ_ERR_INVALID, "row mode %d outside 0..3", mode);
     h->row_mode = mode;
+    return VLQ_OK;
+}
+
+int vlq_line_set_scan_parts(vlq_line_t h, int parts) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    if (parts < 0 || parts > 64) return fail(VLQ_ERR_INVALID, "scan parts %d outside 0..64", parts);
+    h->scan_parts = parts;
     return VLQ_OK;
 }
 
@@ -162,18 +192,21 @@ int vlq_line_set_coarse_centroids(vlq_line_t h, const float* c) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     h->have_graph = false;
     h->term2h_valid = false;
+    drop_consts(h);
     return vlq_ivfpq_set_coarse_centroids(h->base, c);
 }
 
 int vlq_line_set_pq_centroids(vlq_line_t h, const float* c) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     h->term2h_valid = false;
+    drop_consts(h);
     return vlq_ivfpq_set_pq_centroids(h->base, c);
 }
 
 int vlq_line_set_lambda_codebook(vlq_line_t h, const float* li) {
     if (!h || !li) return fail(VLQ_ERR_INVALID, "null argument");
     TRY(set_dev(h->base));
+    drop_consts(h);
     TRY(h->lambda_info.reserve(256 * 4));            // the 16-byte scan copies all 256 slots into LDS
     HIP_TRY(hipMemsetAsync(h->lambda_info.p, 0, 256 * 4, h->base->stream));
     HIP_TRY(hipMemcpyAsync(h->lambda_info.p, li, (size_t)h->nlambda * 4, hipMemcpyDefault, h->base->stream));
@@ -187,6 +220,7 @@ int vlq_line_set_lambda_codebook(vlq_line_t h, const float* li) {
 int vlq_line_set_graph(vlq_line_t h, const int32_t* ei, const float* ed) {
     if (!h || !ei || !ed) return fail(VLQ_ERR_INVALID, "null argument");
     TRY(set_dev(h->base));
+    drop_consts(h);
     const size_t n = (size_t)h->nlines;
     std::vector<int32_t> chk(n);
     HIP_TRY(hipMemcpy(chk.data(), ei, n * 4, hipMemcpyDefault));
@@ -292,6 +326,7 @@ int vlq_line_set_lists(vlq_line_t h, const uint8_t* codes, const uint8_t* lambda
     if (!h || !line_offsets) return fail(VLQ_ERR_INVALID, "null argument");
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
+    drop_consts(h);
     std::vector<int64_t> off((size_t)h->nlines + 1);
     HIP_TRY(hipMemcpy(off.data(), line_offsets, off.size() * 8, hipMemcpyDefault));
     if (off[0] != 0) return fail(VLQ_ERR_INVALID, "line_offsets[0] != 0");
@@ -334,6 +369,7 @@ int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids) {
     const void* idd = nullptr;
     if (xids) TRY(stage_in(b, xids, (size_t)n * 8, h->ws_keys, &idd));
     vlq::ListStore ls = line_store(h);
+    drop_consts(h);              // (the append may move every list; the constants are rebuilt before the next search)
     int64_t placed = 0;
     TRY(vlq::lists_append(ls, h->ws_append, n, nullptr, h->ws_line.as<int32_t>(), h->ws_codes.as<uint8_t>(),
                           h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream, &placed));
@@ -427,6 +463,10 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
                                 sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream,
                                 h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
                                 with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() : nullptr, h->ws_sel_cnt.as<int32_t>());
+        // the stored codes' share of the distance (line16c.hip), once per database state
+        const bool use_consts = !rebuilt_rows && (h->row_mode == 0 || h->row_mode == 3) && with_meta && b->M == 16 &&
+                                b->ksub == 256 && w1 <= 1024 && h->ntotal > 0;
+        if (use_consts) TRY(ensure_consts(h, fp16));
         // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
         vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
                               b->ws_qtab.as<float>(), b->stream);
@@ -447,6 +487,15 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
         a.ncode = h->stats.as<unsigned long long>();
         a.nq = ni; a.w1 = w1; a.k = k; a.M = b->M; a.ksub = b->ksub; a.nedge = h->nedge;
         a.max_line_codes = VLQ_LINE_MAX_CODES;
+        a.nprobe = nprobe;
+        if (use_consts) {
+            a.pconst = fp16 ? h->pconsth.as<float>() : h->pconst.as<float>();
+            a.nparts = h->scan_parts > 0 ? h->scan_parts : vlq::line16c_parts(ni, k, 8);
+            if (a.nparts > 1) {
+                TRY(h->ws_part_keys.reserve((size_t)ni * a.nparts * k * 8));
+                a.part_keys = h->ws_part_keys.as<unsigned long long>();
+            }
+        }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (h->prof) {
             auto get = [&]() { hipEvent_t e = nullptr; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr; return e; };
@@ -457,6 +506,8 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
             a.coarse = b->coarse.as<float>(); a.pq_cent = b->pq.as<float>(); a.pq_rnorm = b->rnorm.as<float>();
             a.term2 = nullptr;
             vlq::launch_line16r_scan(a, b->dsub, b->stream);
+        } else if (use_consts && vlq::line16c_supports(a)) {
+            vlq::launch_line16c_scan(a, b->stream);
         } else {
             vlq::launch_line_scan(a, b->stream);
         }
@@ -498,11 +549,14 @@ int vlq_line_stats(vlq_line_t h, uint64_t* ncode, int reset) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     vlq_ivfpq_t b = h->base;
     TRY(set_dev(b));
-    unsigned long long st[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 16, hipMemcpyDeviceToHost, b->stream));
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 64, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (ncode) *ncode = st[0];
-    if (reset) HIP_TRY(hipMemsetAsync(h->stats.p, 0, 16, b->stream));
+    if (getenv("VLQ_L16C_TIMING") && st[5])
+        fprintf(stderr, "[l16c timing] per workgroup: prologue %.2f us, loop %.2f us, tail %.2f us (%llu workgroups)\n",
+                st[2] * 0.01 / st[5], st[3] * 0.01 / st[5], st[4] * 0.01 / st[5], st[5]);
+    if (reset) HIP_TRY(hipMemsetAsync(h->stats.p, 0, 64, b->stream));
     return VLQ_OK;
 }
 

@@ -283,6 +283,10 @@ class GpuVLQ:
         (speed only, identical results; include/vlq_line.h)"""
         check(lib().vlq_line_set_row_mode(self._h, C.c_int(int(mode))))
 
+    def set_scan_parts(self, parts):
+        """workgroups per query of the default 16-byte scan (0 = automatic); never changes a result"""
+        check(lib().vlq_line_set_scan_parts(self._h, C.c_int(int(parts))))
+
     def set_graph(self, edge_info, edge_dist):
         pe, _a = _ptr(edge_info, np.int32)
         pd, _b = _ptr(edge_dist, np.float32)
