@@ -305,7 +305,25 @@ def sources_sha():
     return hh.hexdigest()
 
 
-def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
+def vlq_traffic():
+    """HBM bytes per launch of the VLQ scan from the filed counter passes -- quoted only while the kernel sources they were
+    measured on are unchanged (same rule as the headline's roofline.traffic)."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_vlq_traffic.json")) as fh:
+            rec = json.load(fh)
+        hh = hashlib.sha256()
+        for f in rec["sources"]:
+            with open(os.path.join(ROOT, "vector_line_quantization_amd", "csrc", f), "rb") as fh:
+                hh.update(fh.read())
+        if hh.hexdigest() != rec["sources_sha"]:
+            return {}
+        return {name: rec[name]["bytes"] for name in ("fp32_tables", "float16_tables")}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5, nsample=64):
     """The fork's VLQ index at the reference driver's geometry (65 536 centroids x 64 edges =
     4.19 M lines, nLambda 256, M = 16 x 8 bit, nprobe 64, w1 1024, k 128; gpu/test/deep1b16_query.cpp:
     206-208,326,337-340) with a reduced database: build on the device, search with fp32 and with float16
@@ -342,6 +360,9 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
     xq[:nq // 2] = first[:nq // 2]                      # half the batch: stored vectors
     D = torch.empty((nq, k), dtype=torch.float32, device=dev)
     I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    # queries checked bit for bit against the oracle in every leg: half stored vectors, half fresh ones
+    sample = np.r_[0:nsample // 2, nq // 2:nq // 2 + nsample - nsample // 2]
+    cent_h, pq_h = cent.cpu().numpy(), pq.cpu().numpy()
     out = {"workload": "VLQ, SURVEY C5 geometry: d=96, 65536 centroids x 64 edges, nLambda=256, M=16x8bit, nprobe=64, w1=1024, "
                        "k=128, %d queries per batch, %d synthetic vectors (reduced from 1 B; full size: profiles/)" % (nq, nb),
            "build_s": build_s}
@@ -359,8 +380,7 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
         ncode = g.stats(reset=True) / reps
         Ih = I.cpu().numpy()
         s1, sk = scale_checks.self_hit(Ih[:nq // 2])
-        chk = scale_checks.check_vlq_sample(g, xq[np.r_[0:2, nq // 2:nq // 2 + 2]].cpu().numpy(), nprobe, w1, k, cent.cpu().numpy(),
-                                            pq.cpu().numpy(), lam, ei, ed, fp16=fp16)
+        chk = scale_checks.check_vlq_sample(g, xq[sample].cpu().numpy(), nprobe, w1, k, cent_h, pq_h, lam, ei, ed, fp16=fp16)
         out[name] = {"value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
                      "self_hit_in_top_k": sk, "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"]}
     # the same geometry at the reference driver's DATABASE size: 238 codes on every one of the 4.19 M lines
@@ -377,9 +397,9 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
                 torch.arange(nlist * nedge + 1, dtype=torch.int64, device=dev) * per)
     del codes, lams
     peak = 8000.0
-    # bytes from the fabric per scan launch, rocprofv3 --pmc FETCH_SIZE x 2 (profiles/r03_pmc_vlq.txt), quoted only for
-    # the workload and kernels it was measured on
-    pmc_traffic = {"fp32_tables": 44.8e9, "float16_tables": 26.0e9}
+    # bytes from the fabric per scan launch, rocprofv3 --pmc FETCH_SIZE x 2 (profiles/r04_pmc_vlq.txt ->
+    # profiles/r04_vlq_traffic.json), quoted only for the workload and the kernel sources it was measured on
+    pmc_traffic = vlq_traffic()
     for name, fp16 in (("fp32_tables", False), ("float16_tables", True)):
         g.set_float16_tables(fp16)
         for _ in range(2):
@@ -397,22 +417,23 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5):
         g.profile(False)
         kernel_ms = scan_ms / max(1, launches)
         ncode = g.stats(reset=True) / reps
-        chk = scale_checks.check_vlq_sample(g, xq[np.r_[0:2, nq // 2:nq // 2 + 2]].cpu().numpy(), nprobe, w1, k, cent.cpu().numpy(),
-                                            pq.cpu().numpy(), lam, ei, ed, fp16=fp16)
+        chk = scale_checks.check_vlq_sample(g, xq[sample].cpu().numpy(), nprobe, w1, k, cent_h, pq_h, lam, ei, ed, fp16=fp16)
         achieved = ncode * (M + 1) / (kernel_ms * 1e-3) / 1e9
-        traffic = pmc_traffic[name] if nq == 2000 else None
+        traffic = pmc_traffic.get(name) if nq == 2000 else None
         out["codes_1b_" + name] = {
             "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
             "database": "%d synthetic 17-byte codes, %d per line" % (nbig, per),
             "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"],
-            "roofline": {"bound": "hbm", "kernel": "line16h_scan_kernel" if fp16 else "line16_scan_kernel", "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "kernel": "line16c_scan_kernel<2, 8, 2, %s>" % ("true" if fp16 else "false"), "kernel_ms": kernel_ms,
                          "launches": launches, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "algorithmic_bytes": ncode * (M + 1), "traffic": traffic,
                          "frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / peak) if traffic else None,
                          "note": "achieved = scanned codes x 17 B / scan-kernel time (HIP events on the index's stream); the "
-                                 "kernel also reads one table row per kept line (%d KB x %d lines per query) -- the reference's "
-                                 "kernel reads two -- which is what `traffic` (PMC FETCH_SIZE x 2) shows and what bounds it"
-                                 % (8 if fp16 else 16, w1)}}
+                                 "kernel also reads 4 B per code (the stored query-independent la * sum(term 4), line16c.hip) and one "
+                                 "%d KB table row per probed centroid (%d per query; the reference's kernel reads two rows per kept "
+                                 "line, %d per query) -- `traffic` (PMC FETCH_SIZE x 2) shows the sum, read at the rate HBM "
+                                 "delivers for random ~4 KB segments (5.5-5.8 TB/s, MI355X_MICROARCH.md)"
+                                 % (8 if fp16 else 16, nprobe, w1)}}
     return out
 
 
