@@ -33,6 +33,8 @@ class FaissException : public std::exception {
   do { if (!(X)) { FAISS_THROW_FMT("Error: '%s' failed", #X); } } while (false)
 #define FAISS_THROW_IF_NOT_MSG(X, MSG) \
   do { if (!(X)) { FAISS_THROW_FMT("Error: '%s' failed: " MSG, #X); } } while (false)
+#define FAISS_THROW_IF_NOT_FMT(X, FMT, ...) \
+  do { if (!(X)) { FAISS_THROW_FMT("Error: '%s' failed: " FMT, #X, __VA_ARGS__); } } while (false)
 #define FAISS_ASSERT(X)                                                              \
   do {                                                                               \
     if (!(X)) {                                                                      \

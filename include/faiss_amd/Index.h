@@ -48,6 +48,19 @@ struct Index {
   virtual void reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
     for (idx_t i = 0; i < ni; i++) reconstruct(i0 + i, recons + i * d);
   }
+  /// search, then reconstruct every result (Index.h:167, Index.cpp:57-74): the fork declares it right behind
+  /// reconstruct_n, so it takes the same vtable slot here; a missing result (label -1) is filled with 0xff bytes
+  virtual void search_and_reconstruct(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels,
+                                      float* recons) const {
+    search(n, x, k, distances, labels);
+    for (idx_t i = 0; i < n; ++i)
+      for (idx_t j = 0; j < k; ++j) {
+        const idx_t ij = i * k + j, key = labels[ij];
+        float* r = recons + ij * d;
+        if (key < 0) memset(r, -1, sizeof(*r) * d);
+        else reconstruct(key, r);
+      }
+  }
   /// residual = x - reconstruct(key) (Index.cpp:76-81)
   void compute_residual(const float* x, float* residual, idx_t key) const {
     reconstruct(key, residual);

@@ -55,6 +55,22 @@ struct IndexIVF : Index {
   }
   void add(idx_t n, const float* x) override { add_with_ids(n, x, nullptr); }
   virtual void train_residual(idx_t, const float*) {}
+  /// IndexIVF::merge_from (IndexIVF.cpp:150-177): moves the other index's lists into this one, `add_id` added to its ids
+  virtual void merge_from_residuals(IndexIVF&) { FAISS_THROW_MSG("merge_from_residuals not implemented for this type of index"); }
+  void merge_from(IndexIVF& other, idx_t add_id) {
+    FAISS_THROW_IF_NOT(other.d == d && other.nlist == nlist);
+    FAISS_THROW_IF_NOT_MSG(!maintain_direct_map && !other.maintain_direct_map, "direct map copy not implemented");
+    FAISS_THROW_IF_NOT_MSG(typeid(*this) == typeid(other), "can only merge indexes of the same type");
+    for (size_t i = 0; i < nlist; i++) {
+      std::vector<long>& src = other.ids[i];
+      std::vector<long>& dest = ids[i];
+      for (size_t j = 0; j < src.size(); j++) dest.push_back(src[j] + add_id);
+      src.clear();
+    }
+    merge_from_residuals(other);
+    ntotal += other.ntotal;
+    other.ntotal = 0;
+  }
   size_t get_list_size(size_t list_no) const { return ids[list_no].size(); }
   /// 1 = perfectly balanced (IndexIVF.cpp:140-147)
   double imbalance_factor() const {

@@ -7,6 +7,9 @@
 #include <cstdint>
 #include <vector>
 
+#include <algorithm>
+
+#include "AuxIndexStructures.h"
 #include "IndexFlat.h"
 #include "IndexIVF.h"
 #include "IndexPQ.h"
@@ -53,12 +56,18 @@ struct IndexIVFPQ : IndexIVF {
     do_polysemous_training = false;
     polysemous_ht = 0;
   }
+  /// IndexIVFPQ() (IndexIVFPQ.cpp:1227-1236): the run-time fields only; read_index / the caller fills in the rest
+  IndexIVFPQ() : by_residual(true), use_precomputed_table(0), code_size(0), do_polysemous_training(false),
+                 polysemous_training(nullptr), scan_table_threshold(0), max_codes(0), polysemous_ht(0) {}
   ~IndexIVFPQ() override { if (h_) vlq_ivfpq_destroy(h_); }
   IndexIVFPQ(const IndexIVFPQ&) = delete;
   IndexIVFPQ& operator=(const IndexIVFPQ&) = delete;
 
-  /// train_residual_o (IndexIVFPQ.cpp:73-132)
-  void train_residual(idx_t n, const float* x) override {
+  void train_residual(idx_t n, const float* x) override { train_residual_o(n, x, nullptr); }
+
+  /// train_residual_o (IndexIVFPQ.cpp:73-132); residuals_2 (optional, [n'][d] with n' = the possibly subsampled training
+  /// set size): training vector minus its PQ reconstruction, what IVFPQR trains its refinement quantizer on
+  void train_residual_o(idx_t n, const float* x, float* residuals_2) {
     size_t ns = n;
     std::vector<float> xs = maybe_subsample(d, &ns, pq.cp.max_points_per_centroid * pq.ksub, x, pq.cp.seed);
     std::vector<float> trainset;
@@ -74,6 +83,21 @@ struct IndexIVFPQ : IndexIVF {
     pq.train((int)ns, trainset.data());
     FAISS_THROW_IF_NOT_MSG(!do_polysemous_training, "polysemous training is outside the built path");
     hdirty_ = true;
+    if (residuals_2) {   // IndexIVFPQ.cpp:113-125: codes of the training set itself (no coarse step), decoded and subtracted
+      std::vector<uint8_t> tc(ns * pq.code_size);
+      std::vector<int64_t> zero(ns, 0);
+      if (ns > 0) {   // pq.compute_codes of the training set as it stands: the device encoder without its residual step
+        sync_(false);
+        VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 0, 0, (int64_t)max_codes));
+        VLQ_CHECK(vlq_ivfpq_encode_preassigned(h_, (int64_t)ns, trainset.data(), zero.data(), tc.data()));
+        sync_(false);                                // puts by_residual back
+      }
+      for (size_t i = 0; i < ns; i++) {
+        float* res = residuals_2 + i * d;
+        pq.decode(&tc[i * pq.code_size], res);
+        for (int j = 0; j < d; j++) res[j] = trainset[i * d + j] - res[j];
+      }
+    }
     if (by_residual) precompute_table();
   }
 
@@ -134,6 +158,149 @@ struct IndexIVFPQ : IndexIVF {
     IndexIVF::reset();
     for (auto& c : codes) c.clear();
     ldirty_ = true;
+  }
+
+  /// code of one vector for list `key` (IndexIVFPQ.cpp:136-144); host-side, for single vectors
+  void encode(long key, const float* x, uint8_t* code) const {
+    if (by_residual) {
+      std::vector<float> r(d);
+      quantizer->compute_residual(x, r.data(), key);
+      pq.compute_code(r.data(), code);
+    } else {
+      pq.compute_code(x, code);
+    }
+  }
+
+  /// encode_multiple (IndexIVFPQ.cpp:150-167) on the device: compute_keys = true also fills keys with the nearest list
+  void encode_multiple(size_t n, long* keys, const float* x, uint8_t* xcodes, bool compute_keys = false) const {
+    if (n == 0) return;
+    sync_(false);
+    if (compute_keys) VLQ_CHECK(vlq_ivfpq_encode(h_, (int64_t)n, x, (int64_t*)keys, xcodes));
+    else VLQ_CHECK(vlq_ivfpq_encode_preassigned(h_, (int64_t)n, x, (const int64_t*)keys, xcodes));
+  }
+
+  /// inverse of encode_multiple (IndexIVFPQ.cpp:169-183)
+  void decode_multiple(size_t n, const long* keys, const uint8_t* xcodes, float* x) const {
+    pq.decode(xcodes, x, n);
+    if (by_residual) {
+      std::vector<float> centroid(d);
+      for (size_t i = 0; i < n; i++) {
+        quantizer->reconstruct(keys[i], centroid.data());
+        float* xi = x + i * d;
+        for (int j = 0; j < d; j++) xi[j] += centroid[j];
+      }
+    }
+  }
+
+  /// IndexIVFPQ.cpp:278-303: every stored vector whose id lies in [i0, i0 + ni)
+  void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override {
+    FAISS_THROW_IF_NOT(ni == 0 || (i0 >= 0 && i0 + ni <= ntotal));
+    std::vector<float> centroid(d);
+    for (size_t key = 0; key < nlist; key++) {
+      const std::vector<long>& idlist = ids[key];
+      const uint8_t* code_line = codes[key].data();
+      for (size_t ofs = 0; ofs < idlist.size(); ofs++) {
+        const long id = idlist[ofs];
+        if (!(id >= i0 && id < i0 + ni)) continue;
+        float* r = recons + (size_t)d * (id - i0);
+        pq.decode(code_line + ofs * pq.code_size, r);
+        if (by_residual) {
+          quantizer->reconstruct((idx_t)key, centroid.data());
+          for (int j = 0; j < d; j++) r[j] += centroid[j];
+        }
+      }
+    }
+  }
+
+  /// IndexIVFPQ.cpp:1195-1224: a removed entry is replaced by the list's last one
+  long remove_ids(const IDSelector& sel) override {
+    FAISS_THROW_IF_NOT_MSG(!maintain_direct_map, "direct map remove not implemented");
+    long nremove = 0;
+    for (size_t i = 0; i < nlist; i++) {
+      std::vector<long>& idsi = ids[i];
+      uint8_t* codesi = codes[i].data();
+      long l = (long)idsi.size(), j = 0;
+      while (j < l) {
+        if (sel.is_member(idsi[j])) {
+          l--;
+          idsi[j] = idsi[l];
+          memmove(codesi + j * code_size, codesi + l * code_size, code_size);
+        } else {
+          j++;
+        }
+      }
+      if (l < (long)idsi.size()) {
+        nremove += (long)idsi.size() - l;
+        idsi.resize(l);
+        codes[i].resize(l * code_size);
+      }
+    }
+    ntotal -= nremove;
+    if (nremove) ldirty_ = true;
+    return nremove;
+  }
+
+  /// groups of stored vectors with identical codes in the same list (IndexIVFPQ.cpp:1239-1280): lims[0..ngroup],
+  /// dup_ids[lims[g] .. lims[g+1]) = the ids of group g; returns the number of groups
+  size_t find_duplicates(idx_t* dup_ids, size_t* lims) const {
+    size_t ngroup = 0;
+    lims[0] = 0;
+    for (size_t list_no = 0; list_no < nlist; list_no++) {
+      const size_t n = ids[list_no].size();
+      const uint8_t* tab = codes[list_no].data();
+      const size_t cs = code_size;
+      std::vector<int> ord(n);
+      for (size_t i = 0; i < n; i++) ord[i] = (int)i;
+      auto cmp = [tab, cs](int a, int b) { return memcmp(tab + a * cs, tab + b * cs, cs); };
+      std::sort(ord.begin(), ord.end(), [&](int a, int b) { return cmp(a, b) > 0; });   // CodeCmp: descending by bytes
+      const long* list_ids = ids[list_no].data();
+      int prev = -1;   // elements prev .. i-1 are equal
+      for (size_t i = 0; i < n; i++) {
+        if (prev >= 0 && cmp(ord[prev], ord[i]) == 0) {
+          if ((size_t)prev + 1 == i) {   // a new group starts
+            ngroup++;
+            lims[ngroup] = lims[ngroup - 1];
+            dup_ids[lims[ngroup]++] = list_ids[ord[prev]];
+          }
+          dup_ids[lims[ngroup]++] = list_ids[ord[i]];
+        } else {
+          prev = (int)i;
+        }
+      }
+    }
+    return ngroup;
+  }
+
+  /// moves the other index's codes behind this one's (IndexIVFPQ.cpp:327-335; the ids move in IndexIVF::merge_from)
+  void merge_from_residuals(IndexIVF& other_in) override {
+    IndexIVFPQ& other = dynamic_cast<IndexIVFPQ&>(other_in);
+    for (size_t i = 0; i < nlist; i++) {
+      codes[i].insert(codes[i].end(), other.codes[i].begin(), other.codes[i].end());
+      other.codes[i].clear();
+    }
+    ldirty_ = other.ldirty_ = true;
+  }
+
+  /// copies the entries with a1 <= id < a2 (subset_type 0; what gpu/GpuAutoTune.cpp:231-283 shards an index with).
+  /// IndexIVFPQ.h:154-158 also documents subset_type 1 (id % a1 == a2), but the reference's loop (IndexIVFPQ.cpp:337-361)
+  /// copies nothing for it; the same happens here, so that a caller sees the reference's behaviour
+  void copy_subset_to(IndexIVFPQ& other, int subset_type, long a1, long a2) const {
+    FAISS_THROW_IF_NOT(nlist == other.nlist);
+    FAISS_THROW_IF_NOT(!other.maintain_direct_map);
+    const size_t cs = pq.code_size;
+    for (size_t list_no = 0; list_no < nlist; list_no++) {
+      const std::vector<long>& ids_in = ids[list_no];
+      const std::vector<uint8_t>& codes_in = codes[list_no];
+      for (size_t i = 0; i < ids_in.size(); i++) {
+        const long id = ids_in[i];
+        if (subset_type == 0 && a1 <= id && id < a2) {
+          other.ids[list_no].push_back(id);
+          other.codes[list_no].insert(other.codes[list_no].end(), codes_in.begin() + i * cs, codes_in.begin() + (i + 1) * cs);
+          other.ntotal++;
+        }
+      }
+    }
+    other.ldirty_ = true;
   }
   void reconstruct(idx_t key, float* recons) const override {
     FAISS_THROW_IF_NOT(maintain_direct_map && key >= 0 && key < (idx_t)direct_map.size());

@@ -41,6 +41,23 @@ struct ProductQuantizer {
       memcpy(get_centroids(m, 0), clus.centroids.data(), ksub * dsub * sizeof(float));
     }
   }
+  /// nearest centroid per sub-quantizer, first minimum wins (ProductQuantizer.cpp:311-336: fvec_L2sqr_ny + strict <).
+  /// Host-side, one vector at a time; bulk encoding goes through the device (IndexIVFPQ::encode_multiple).
+  void compute_code(const float* x, uint8_t* code) const {
+    FAISS_THROW_IF_NOT_MSG(byte_per_idx == 1, "only one byte per sub-quantizer index is built");
+    for (size_t m = 0; m < M; m++) {
+      const float* xs = x + m * dsub;
+      float best = 3.402823466e+38f;
+      size_t bi = 0;
+      for (size_t j = 0; j < ksub; j++) {
+        const float* c = get_centroids(m, j);
+        float dis = 0;
+        for (size_t i = 0; i < dsub; i++) { const float t = xs[i] - c[i]; dis += t * t; }
+        if (dis < best) { best = dis; bi = j; }
+      }
+      code[m] = (uint8_t)bi;
+    }
+  }
   void decode(const uint8_t* code, float* x) const {
     for (size_t m = 0; m < M; m++) memcpy(x + m * dsub, get_centroids(m, code[m]), sizeof(float) * dsub);
   }

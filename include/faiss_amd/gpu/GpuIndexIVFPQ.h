@@ -250,19 +250,25 @@ class GpuIndexIVFPQ : public GpuIndex {
     }
   }
 
+  /// gpu/GpuIndexIVFPQ.h:120-131; a VLQ index's lists are its lines (listId = centroid * nedge + edge, as in the fork)
   int getListLength(int listId) const {
     int64_t len = 0;
-    VLQ_CHECK(vlq_ivfpq_list_length(h_, listId, &len));
+    if (line_) VLQ_CHECK(vlq_line_list_length(line_, listId, &len));
+    else VLQ_CHECK(vlq_ivfpq_list_length(h_, listId, &len));
     return (int)len;
   }
   std::vector<unsigned char> getListCodes(int listId) const {
     std::vector<unsigned char> c((size_t)getListLength(listId) * subQuantizers_);
-    VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, c.data(), nullptr));
+    if (c.empty()) return c;
+    if (line_) VLQ_CHECK(vlq_line_get_list(line_, listId, c.data(), nullptr, nullptr));
+    else VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, c.data(), nullptr));
     return c;
   }
   std::vector<long> getListIndices(int listId) const {
     std::vector<int64_t> v((size_t)getListLength(listId));
-    VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, nullptr, v.data()));
+    if (v.empty()) return std::vector<long>();
+    if (line_) VLQ_CHECK(vlq_line_get_list(line_, listId, nullptr, nullptr, v.data()));
+    else VLQ_CHECK(vlq_ivfpq_get_list(h_, listId, nullptr, v.data()));
     return std::vector<long>(v.begin(), v.end());
   }
   vlq_ivfpq_t handle() const { return h_; }
@@ -345,24 +351,64 @@ class GpuIndexIVFPQ : public GpuIndex {
     }
     fn.write((const char*)counts.data(), counts.size() * sizeof(int));
   }
-  /// all lines, or only the list range of `rank` out of `pronum` processes: foreign lines stay
-  /// empty, exactly what the fork's per-rank loader does (gpu/GpuIndexIVFPQ.cu:2106-2163)
-  void readDbFromFile(const std::string& name, int pronum = 1, int rank = 0) {
+  /// readDbFromFile (gpu/GpuIndexIVFPQ.cu:1847-1904): every line of the .dbIdx / .dblas / .dbcodes / .dbcount set
+  void readDbFromFile(const std::string& name) { readDb_(name, 1, 0); }
+  /// :1918-2010: the same with the caller's total count (the reference sizes its device buffers with it and then walks
+  /// the whole .dbcount table): nb must cover the stored vectors
+  void readDbFromFile(const std::string& name, size_t nb) {
+    readDb_(name, 1, 0);
+    FAISS_THROW_IF_NOT_FMT((size_t)ntotal <= nb, "readDbFromFile: nb=%zu but the files hold %ld vectors", nb, ntotal);
+  }
+  /// :2214-2309 / :2106-2212 -- the per-rank loaders of the fork's MPI drivers (gpu/test/deep1b16_query.cpp:270,
+  /// sift1b16_query.cpp:323: `index.readDbFromFile(prename, 0, numproces, rank)`): rank r of pronum keeps the lines
+  /// [(nl / pronum) * r, (nl / pronum) * (r + 1)) with nl = nlist * nedge -- the reference's own arithmetic (:2132-2141),
+  /// remainder lines of a non-dividing pronum are dropped there too -- every other line stays empty; begin_ / end_ =
+  /// the centroid range (:2127-2134).  nb is ignored on input, as in the reference (it overwrites it with the count)
+  void readDbFromFile(const std::string& name, int pronum, int rank) { readDb_(name, pronum, rank); }
+  void readDbFromFile(const std::string& name, size_t /*nb*/, int pronum, int rank) { readDb_(name, pronum, rank); }
+
+  /// lambda bytes of one line (gpu/GpuIndexIVFPQ.cu:2332-2338)
+  std::vector<unsigned char> getListLambdas(int listId) const {
     FAISS_THROW_IF_NOT_MSG(line_, "not a VLQ index");
+    int64_t len = 0;
+    VLQ_CHECK(vlq_line_list_length(line_, listId, &len));
+    std::vector<unsigned char> l((size_t)len);
+    if (len > 0) VLQ_CHECK(vlq_line_get_list(line_, listId, nullptr, l.data(), nullptr));
+    return l;
+  }
+
+  /// coarse centroids as a .umem file (gpu/GpuIndexIVFPQ.cu:1760-1771 -> filehelper.cpp:253-280, 344-351): the text
+  /// lines "<num>\n<dim>\n", the float rows from byte 20 (the reference's writer appends the rows a second time behind
+  /// them -- filehelper.cpp:277 -- which no reader looks at; they are written once here)
+  void writeCentroidsToFile(const std::string& name) {
+    FAISS_THROW_IF_NOT_MSG(!coarse_.empty(), "no coarse centroids");
+    std::ofstream f((name + ".umem").c_str(), std::ofstream::binary);
+    FAISS_THROW_IF_NOT_MSG(f.good(), "cannot open the centroid file for writing");
+    f << (size_t)nlist_ << std::endl << (unsigned)d << std::endl;
+    f.seekp(20, std::ios::beg);
+    f.write((const char*)coarse_.data(), (std::streamsize)((size_t)nlist_ * d * sizeof(float)));
+  }
+
+ private:
+  void readDb_(const std::string& name, int pronum, int rank) {
+    FAISS_THROW_IF_NOT_MSG(line_, "not a VLQ index");
+    FAISS_THROW_IF_NOT_FMT(pronum >= 1 && rank >= 0 && rank < pronum, "bad process rank %d of %d", rank, pronum);
     std::ifstream fi((name + ".dbIdx").c_str(), std::ifstream::binary), fl((name + ".dblas").c_str(), std::ifstream::binary),
         fc((name + ".dbcodes").c_str(), std::ifstream::binary), fn((name + ".dbcount").c_str(), std::ifstream::binary);
     FAISS_THROW_IF_NOT_MSG(fi.good() && fl.good() && fc.good() && fn.good(), "cannot open db files");
     const int64_t nl = (int64_t)nlist_ * numedge_;
     std::vector<int> counts(nl);
     fn.read((char*)counts.data(), counts.size() * sizeof(int));
-    begin_ = (int)((int64_t)rank * nl / pronum);
-    end_ = (int)((int64_t)(rank + 1) * nl / pronum);
+    FAISS_THROW_IF_NOT_MSG(fn.good(), "db count file too short");
+    begin_ = (nlist_ / pronum) * rank;
+    end_ = rank == pronum - 1 ? nlist_ - 1 : begin_ + nlist_ / pronum - 1;
+    const int64_t start = (nl / pronum) * rank, stop = pronum == 1 ? nl : start + nl / pronum;   // lines [start, stop)
     std::vector<int64_t> off(nl + 1, 0);
     int64_t skip = 0, take = 0;
     for (int64_t i = 0; i < nl; i++) {
-      const bool mine = i >= begin_ && i < end_;
+      const bool mine = i >= start && i < stop;
       off[i + 1] = off[i] + (mine ? counts[i] : 0);
-      if (i < begin_) skip += counts[i];
+      if (i < start) skip += counts[i];
       if (mine) take += counts[i];
     }
     std::vector<int64_t> ids(take);
@@ -376,7 +422,6 @@ class GpuIndexIVFPQ : public GpuIndex {
     ntotal = take;
   }
 
- private:
   /// GpuIndexIVFPQ::train of the fork (gpu/GpuIndexIVFPQ.cu:1160-1178): coarse k-means,
   /// centroid graph, then trainResidualQuantizer_ (:346-403): lines + lambdas of a
   /// training subset, 1-D k-means of the lambdas, PQ on the residuals to the anchors

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <vector>
 
 #include "faiss_amd/IndexFlat.h"
@@ -14,7 +15,9 @@
 #include "faiss_amd/gpu/GpuClonerOptions.h"
 #include "faiss_amd/gpu/GpuIndexIVFPQ.h"
 #include "faiss_amd/gpu/IndexProxy.h"
+#ifndef VLQ_NO_RCCL   // tests/cpp/Makefile: an image without librccl builds everything but part 2h
 #include "faiss_amd/gpu/RcclShardedIndex.h"
+#endif
 #include "faiss_amd/gpu/StandardGpuResources.h"
 #include "faiss_amd/index_io.h"
 
@@ -148,6 +151,54 @@ int main() {
     std::vector<float> md((size_t)k * nq);
     vlqIndex.merge(parts_n.data(), parts_d.data(), k, nq, 2, md.data(), mn.data());
     EXPECT(md == vdis);
+    {   // the overloads the fork's MPI drivers call (gpu/test/deep1b16_query.cpp:270: readDbFromFile(prename, 0, numproces, rank)),
+        // the reference's partition arithmetic (gpu/GpuIndexIVFPQ.cu:2127-2141: nl / pronum lines per rank, the remainder of a
+        // non-dividing pronum dropped), getListLambdas (:2332-2338) and writeCentroidsToFile (:1760-1771)
+      const int nl = ncentroids * 8;
+      long total3 = 0, whole = 0;
+      for (int i = 0; i < nl; i++) whole += vlqIndex.getListLength(i);
+      for (int r = 0; r < 3; r++) {
+        faiss::gpu::GpuIndexIVFPQ re(&res, d, ncentroids, 16, 8, 8, 32, faiss::METRIC_L2, config);
+        re.readCodebookFromFile("/tmp/vlq_test");
+        re.readDbFromFile("/tmp/vlq_test", 0, 3, r);
+        const int per = nl / 3;
+        long mine = 0;
+        for (int i = 0; i < nl; i++) {
+          const bool in = i >= per * r && i < per * (r + 1);
+          EXPECT(re.getListLength(i) == (in ? vlqIndex.getListLength(i) : 0));
+          if (in) mine += re.getListLength(i);
+        }
+        EXPECT(re.ntotal == mine);
+        EXPECT(re.begin_ == (ncentroids / 3) * r && re.end_ == (r == 2 ? ncentroids - 1 : re.begin_ + ncentroids / 3 - 1));
+        total3 += mine;
+      }
+      long tail = 0;
+      for (int i = (nl / 3) * 3; i < nl; i++) tail += vlqIndex.getListLength(i);
+      EXPECT(total3 + tail == whole);
+      faiss::gpu::GpuIndexIVFPQ re(&res, d, ncentroids, 16, 8, 8, 32, faiss::METRIC_L2, config);
+      re.readCodebookFromFile("/tmp/vlq_test");
+      re.readDbFromFile("/tmp/vlq_test", (size_t)whole);
+      EXPECT(re.ntotal == whole);
+      for (int i = 0; i < nl; i += 7) {
+        EXPECT(re.getListLambdas(i) == vlqIndex.getListLambdas(i));
+        EXPECT(re.getListLambdas(i).size() == (size_t)re.getListLength(i));
+        EXPECT(re.getListCodes(i).size() == (size_t)re.getListLength(i) * 16);
+      }
+      bool threw = false;
+      try { re.readDbFromFile("/tmp/vlq_test", (size_t)1); } catch (const faiss::FaissException&) { threw = true; }
+      EXPECT(threw);
+      vlqIndex.writeCentroidsToFile("/tmp/vlq_test_centroids");
+      std::ifstream cf("/tmp/vlq_test_centroids.umem", std::ifstream::binary);
+      size_t num = 0, dim = 0;
+      cf >> num >> dim;
+      EXPECT(num == (size_t)ncentroids && dim == (size_t)d);
+      cf.seekg(20, std::ios::beg);
+      std::vector<float> cen((size_t)ncentroids * d);
+      cf.read((char*)cen.data(), cen.size() * sizeof(float));
+      EXPECT(cf.good());
+      remove("/tmp/vlq_test_centroids.umem");
+      printf("part 2d: readDbFromFile(name, nb, pronum, rank) / (name, nb), getListLambdas, writeCentroidsToFile ok\n");
+    }
     for (const char* ext : {".ppqt", ".dbIdx", ".dblas", ".dbcodes", ".dbcount"}) remove((std::string("/tmp/vlq_test") + ext).c_str());
     // returned distances omit |q|^2 (gpu/impl/Distance.cu:286-291): adding it back gives >= 0
     for (int q = 0; q < 10; q++) {
@@ -278,6 +329,7 @@ int main() {
   // part 2h: the RCCL host in C++ (north star: "host code stays C++ ... RCCL all-gather of per-shard top-k"):
   // replicas, ceil(n / G) slices, one grouped all-gather per output array.  One GPU on the box = one rank; the slice
   // arithmetic for G > 1 is checked on its own.
+#ifndef VLQ_NO_RCCL
   {
     long lo, hi, per;
     faiss::gpu::RcclShardedIndex::sliceOf(10000, 8, 7, &lo, &hi, &per);
@@ -300,6 +352,7 @@ int main() {
     EXPECT(std::equal(sn.begin(), sn.begin() + 40 * k, nns.begin()) && std::equal(sd.begin(), sd.begin() + 40 * k, dis.begin()));
     printf("part 2h: RcclShardedIndex (%d rank): rows gathered over RCCL equal the single index\n", sharded.numReplicas());
   }
+#endif
 
   // part 2c: inverted multi-index coarse quantizer (the "IMI2x.." indexes of
   // tests/sift1b_imi_pq.cpp:225-236): quantizer_trains_alone, table type 2

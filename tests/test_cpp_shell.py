@@ -48,6 +48,29 @@ def test_shell_on_gpu():
     assert "all ok" in p.stdout
 
 
+@pytest.mark.gpu
+def test_codec_and_surrounding_members_on_gpu():
+    """tests/cpp/test_ivfpq_codec.cpp: the reference's tests/test_ivfpq_codec.cpp:27-65 replayed against faiss_amd
+    (encode_multiple on the device), then reconstruct_n / search_and_reconstruct / find_duplicates / copy_subset_to /
+    merge_from / remove_ids / train_residual_o / the default constructor against host recomputations."""
+    _build()
+    p = subprocess.run([os.path.join(CPP, "test_ivfpq_codec")], capture_output=True, text=True, timeout=900)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all ok" in p.stdout
+
+
+def test_reference_vlq_drivers_compile_against_our_headers():
+    """gpu/test/deep1b16_query.cpp / sift1b16_query.cpp: main()'s body without its MPI_* lines, taken from the reference
+    tree at build time (nothing of it is kept in the repository), must compile against include/faiss_amd alone --
+    incl. `index.readDbFromFile(prename, 0, numproces, rank)` (deep1b16_query.cpp:270)."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree not available here")
+    subprocess.check_call(["make", "-s", "-C", CPP, "driver_calls"])
+    for name in ("deep1b16_query", "sift1b16_query"):
+        assert os.path.exists(os.path.join(CPP, "ref_drivers", name + "_calls.ok"))
+
+
 def test_gpu_shell_builds_against_reference_headers():
     """the GPU shell compiles against the REFERENCE's own CPU
     headers and links with the reference's own CPU library (build container only)."""
