@@ -12,7 +12,11 @@ shutil.copy(os.path.join(SRC, "bench.json"), dst("bench.json"))
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), dst("bench_under_rocprof.json"))
 shutil.copy(one("trace/**/*kernel_stats.csv"), dst("bench_kernel_stats.csv"))
 shutil.copy(os.path.join(SRC, "pmc_summary.txt"), dst("pmc_summary.txt"))
-shutil.copy(os.path.join(SRC, "pmc2_summary.txt"), dst("pmc_summary_second_dataset.txt"))
+# r01-r03: the second pass ran the low-intrinsic-dimension data beside a G1 headline; since r04 the headline IS that data
+# and the second pass is G1 (bench.py's first_dataset leg)
+shutil.copy(os.path.join(SRC, "pmc2_summary.txt"), dst("pmc_summary_first_dataset.txt" if R >= "r04" else "pmc_summary_second_dataset.txt"))
+if os.path.exists(os.path.join(SRC, "pmc_owned_summary.txt")):
+    shutil.copy(os.path.join(SRC, "pmc_owned_summary.txt"), dst("pmc_summary_owned_schedule.txt"))
 shutil.copy(os.path.join(SRC, "sweep.md"), dst("sweep.md"))
 shutil.copy(one("imi10/**/*kernel_stats.csv"), dst("imi_kernel_stats.csv"))
 shutil.copy(one("imi14/**/*kernel_stats.csv"), dst("imi14_kernel_stats.csv"))
@@ -49,5 +53,7 @@ out = {"kernel": mk.group(1) if mk else "vlq::scan16_kernel<1, ...> (the summary
 sys.path.insert(0, os.path.dirname(HERE))
 import bench
 out["sources_sha256"] = bench.sources_sha()
+# ... and the same setting of the data generator (bench.py defaults at the time of the passes)
+out["generator"] = [0.005, 12, 0.4] if R >= "r04" else list(bench.G1_FLAGS)
 json.dump(out, open(dst("scan_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -5,7 +5,7 @@
 # -> gpurun_out/r02/...   then copy the summaries into profiles/ (python profiles/collect.py r02).
 # Counter passes run without tracing domains.
 set -e
-R=${1:-r03}
+R=${1:-r04}
 PART=${2:-ab}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -19,9 +19,13 @@ $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- pyt
 echo "trace done" >&2
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc --no-second-dataset) > $OUT/pmc.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
-# the second data set of bench.py (low intrinsic dimension: little probe overlap between queries)
-(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc2 --no-second-dataset --sigma 0.005 --rank 12 --spread 0.4) > $OUT/pmc2.log 2>&1
+# generator G1 as rounds 1-3 ran it (bench.py's first_dataset leg: sigma 0.03 isotropic, neighbouring queries share most probes)
+(cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc2 --no-second-dataset --sigma 0.03 --rank 0 --spread 0) > $OUT/pmc2.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc2 > $OUT/pmc2_summary.txt
+# the list-owned schedule's second build (scan16o.hip) on the headline data: the counters filed with the decision not to
+# make it the default
+(cd $REPO && VLQ_SCAN_SCHEDULE=3 $T 600 bash profiles/pmc_passes.sh $OUT/pmc_owned --no-second-dataset) > $OUT/pmc_owned.log 2>&1
+python $REPO/profiles/summarize_pmc.py $OUT/pmc_owned > $OUT/pmc_owned_summary.txt
 echo "pmc done" >&2
 fi
 if [[ $PART == *b* ]]; then

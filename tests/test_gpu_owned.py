@@ -11,9 +11,15 @@ from util import bits
 
 pytestmark = pytest.mark.gpu
 
+import os
+# 2: first build (scan16.hip OWNED), 3 / 4: second build (scan16o.hip, one / two table buffers); the whole module runs once per
+# value through the parametrised fixture below
+SCHEDS = [int(v) for v in os.environ.get("VLQ_TEST_OWNED_SCHEDULES", "2,3,4").split(",")]
 
-@pytest.fixture(scope="module")
-def world():
+
+@pytest.fixture(scope="module", params=SCHEDS)
+def world(request):
+    SCHED = request.param
     rng = np.random.default_rng(77)
     d, nlist, M, nb, nq = 128, 512, 16, 90000, 2500
     centres = rng.random((60, d), dtype=np.float32)
@@ -28,7 +34,7 @@ def world():
     ox = OracleIndex(d, nlist, M, 8, coarse, pq)
     ox.add(xb, canonical=True)
     gs = []
-    for mode in (1, 2):
+    for mode in (1, SCHED):
         g = vlq.GpuIVFPQ(d, nlist, M, 8)
         g.set_coarse_centroids(coarse)
         g.set_pq_centroids(pq)

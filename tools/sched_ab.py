@@ -12,6 +12,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda", 0)
 base = argparse.Namespace(nq=10000, nb=1000000, nt=100000, d=128, nlist=4096, M=16, nprobe=32, k=10, sigma=0.03,
                           gmm_centres=2000, rank=0, spread=0.0)
+MODES = [int(v) for v in os.environ.get("MODES", "1,2,3,4").split(",")]
 for name, kw in (("G1", {}), ("second", dict(sigma=0.005, rank=12, spread=0.4))):
     a = copy.copy(base)
     for k_, v in kw.items():
@@ -22,7 +23,7 @@ for name, kw in (("G1", {}), ("second", dict(sigma=0.005, rank=12, spread=0.4)))
     D = torch.empty((a.nq, a.k), dtype=torch.float32, device=dev); I = torch.empty((a.nq, a.k), dtype=torch.int64, device=dev)
     ref = None
     for k in (a.k, 100):
-        for mode in (1, 2):
+        for mode in MODES:
             g.set_scan_schedule(mode)
             Dk = torch.empty((a.nq, k), dtype=torch.float32, device=dev); Ik = torch.empty((a.nq, k), dtype=torch.int64, device=dev)
             for _ in range(3): g.search(xq, a.nprobe, k, D=Dk, I=Ik)

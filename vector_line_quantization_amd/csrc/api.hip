@@ -478,7 +478,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             // scan schedule (speed only): list-owned = one workgroup per (query, list partition), XCD x
             // serves the lists of partition x, so their term2 rows and codes stay in that XCD's L2
             const int sched = h->scan_schedule ? h->scan_schedule : 1;     // 0 = automatic = query-major (the faster one on every data set measured)
-            const bool owned = sched == 2 && h->imi_nbits == 0 && h->have_rank && h->nlist >= 64 && h->nlist <= 16384 &&
+            const bool owned = sched >= 2 && h->imi_nbits == 0 && h->have_rank && h->nlist >= 64 && h->nlist <= 16384 &&
                                ni >= 1024 && nprobe >= 8 && h->dsub == 8 && h->ntotal >= (int64_t)h->nlist * 24;
             if (owned) {
                 TRY(h->ws_own_hist.reserve(vlq::owned_hist_ints(h->nlist) * sizeof(int)));
@@ -488,6 +488,43 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_part_mask.reserve((size_t)ni + 16));
                 TRY(h->ws_part_keys.reserve((size_t)ni * 8 * k * 8));
                 TRY(h->ws_qtab.reserve((size_t)ni * E * sizeof(float)));
+                if (sched >= 3 && vlq::scan16o_supports(a)) {         // second build: per-probe records, 8-byte item entries
+                    TRY(h->ws_own_recs.reserve((size_t)ni * nprobe * sizeof(vlq::OwnRec)));
+                    TRY(h->ws_own_seg.reserve((size_t)ni * 8 * 4));
+                    TRY(h->ws_own_items.reserve((size_t)ni * 8 * 8));
+                    vlq::ScanArgs ao = a;
+                    ao.qorder = nullptr;
+                    ao.qtab = h->ws_qtab.as<float>();
+                    ao.qtab_scaled = 1;
+                    ao.list_part = h->list_part.as<uint8_t>();
+                    ao.own_count = h->ws_own_count.as<int>();
+                    ao.part_mask = h->ws_part_mask.as<uint8_t>();
+                    ao.part_keys = h->ws_part_keys.as<unsigned long long>();
+                    ao.own_recs = h->ws_own_recs.as<vlq::OwnRec>();
+                    ao.own_items = h->ws_own_items.as<uint2>();
+                    {
+                        StageTimer tq(h, 1);
+                        vlq::launch_owned2_prepare(ao, h->list_rank.as<int>(), h->ws_own_hist.as<int>(), h->ws_own_minr.as<int>(),
+                                                   h->ws_own_seg.as<uint32_t>(), h->ws_own_items.as<uint2>(), h->ws_own_count.as<int>(),
+                                                   h->ws_part_mask.as<uint8_t>(), h->ws_own_recs.as<vlq::OwnRec>(), h->stream);
+                        vlq::launch_qtab16(xi, ni, h->pq_t.as<float>(), h->ws_qtab.as<float>(), h->stream);
+                        tq.stop();
+                    }
+                    if (getenv("VLQ_PHASE_TIMING")) {      // diagnostic: items per partition
+                        static int once = 0;
+                        if (!once++) {
+                            int cnt[8];
+                            (void)hipStreamSynchronize(h->stream);
+                            (void)hipMemcpy(cnt, h->ws_own_count.p, 32, hipMemcpyDeviceToHost);
+                            fprintf(stderr, "[owned] items per partition: %d %d %d %d %d %d %d %d\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7]);
+                        }
+                    }
+                    StageTimer tm(h, 2);
+                    vlq::launch_scan16_owned2(ao, sched == 4 ? 2 : 1, h->stream);
+                    vlq::launch_owned_merge(ao, h->stream);
+                    tm.stop();
+                    continue;
+                }
                 {
                     StageTimer tq(h, 1);   // item ordering + per-query tables are booked with the table stage
                     vlq::launch_owned_order(a.keys, ni, nprobe, h->nlist, h->list_rank.as<int>(), h->list_part.as<uint8_t>(),
@@ -644,18 +681,18 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     h->stream = h->own_stream;
     if (const char* e = getenv("VLQ_SCAN_SCHEDULE")) {    // tests / A-B runs: 1 query-major, 2 list-owned; anything else is ignored
         const int m = atoi(e);
-        if (m >= 0 && m <= 2) h->scan_schedule = m;
+        if (m >= 0 && m <= 4) h->scan_schedule = m;
     }
     if (const char* e = getenv("VLQ_COARSE_SCREEN")) h->coarse_screen = atoi(e);   // 0: f32 MFMA matrix path everywhere (A/B)
     if (const char* e = getenv("VLQ_COARSE_FILTER")) h->coarse_filter = atoi(e);   // 1: filtered coarse stage (A/B; slower)
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
-    int rc = h->stats.reserve(16);
+    int rc = h->stats.reserve(64);     // [0] ncode, [1] flag word; [2..7] phase clocks of instrumented builds (-DVLQ_PHASE_TIMING)
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
     if (rc == VLQ_OK) rc = h->list_len.reserve((size_t)nlist * 8);
     if (rc == VLQ_OK) rc = h->codes.reserve(16);
     if (rc == VLQ_OK) rc = h->ids.reserve(16);
     if (rc != VLQ_OK) { vlq_ivfpq_destroy(h); return rc; }
-    (void)hipMemsetAsync(h->stats.p, 0, 16, h->stream);
+    (void)hipMemsetAsync(h->stats.p, 0, 64, h->stream);
     (void)hipMemsetAsync(h->list_off.p, 0, ((size_t)nlist + 1) * 8, h->stream);
     (void)hipMemsetAsync(h->list_len.p, 0, (size_t)nlist * 8, h->stream);
     (void)hipStreamSynchronize(h->stream);
@@ -672,7 +709,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->term2h, &h->ws_qtabh, &h->coarse, &h->cnorm, &h->pq, &h->pq_t, &h->rnorm, &h->term2, &h->codes, &h->ids,
                       &h->list_off, &h->list_len, &h->list_rank, &h->list_part, &h->ws_own_hist, &h->ws_own_minr, &h->ws_own_order,
-                      &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
+                      &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_own_recs, &h->ws_own_seg, &h->ws_own_items, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
@@ -940,7 +977,7 @@ int vlq_ivfpq_coarse_screen_state(vlq_ivfpq_t h, int* enabled, uint64_t* rows, u
 
 int vlq_ivfpq_set_scan_schedule(vlq_ivfpq_t h, int mode) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
-    if (mode < 0 || mode > 2) return fail(VLQ_ERR_INVALID, "scan schedule %d outside 0..2", mode);
+    if (mode < 0 || mode > 4) return fail(VLQ_ERR_INVALID, "scan schedule %d outside 0..4", mode);
     h->scan_schedule = mode;
     return VLQ_OK;
 }
@@ -1124,14 +1161,17 @@ int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out) {
 int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     TRY(set_dev(h));
-    unsigned long long st[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 16, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 64, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (nq) *nq = h->stat_nq;
     if (ncode) *ncode = st[0];
+    if (st[5] && getenv("VLQ_PHASE_TIMING"))     // only kernels built with -DVLQ_PHASE_TIMING write these
+        fprintf(stderr, "[phase timing] per workgroup: prologue %.2f us, loop %.2f us, tail %.2f us (%llu workgroups)\n",
+                st[2] * 0.01 / st[5], st[3] * 0.01 / st[5], st[4] * 0.01 / st[5], st[5]);
     const int bad = (int)(st[1] & 0xffffffffu);
     if (reset) {
-        HIP_TRY(hipMemsetAsync(h->stats.p, 0, 16, h->stream));
+        HIP_TRY(hipMemsetAsync(h->stats.p, 0, 64, h->stream));
         h->stat_nq = 0;
     } else if (bad) {       // the flag is consumed by the error it raises; the counters stay
         HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(h->stats.p) + 8, 0, 8, h->stream));

@@ -103,9 +103,10 @@ struct vlq_ivfpq_s {
     DevBuf list_part;             // [nlist] u8: partition 0..7 of neighbouring lists, one per XCD (list-owned schedule)
     bool have_rank = false;
     // scan schedule of the 16-byte kernel: 0 = automatic (= 1 today), 1 = one workgroup per query (query-major),
-    // 2 = list-owned (one workgroup per (query, list partition)).  Speed only, never results.
+    // 2 = list-owned (one workgroup per (query, list partition)), 3 = its second build (scan16o.hip; 4: with two
+    // table buffers).  Speed only, never results.
     int scan_schedule = 0;
-    DevBuf ws_own_hist, ws_own_minr, ws_own_order, ws_own_count, ws_part_mask, ws_part_keys;
+    DevBuf ws_own_hist, ws_own_minr, ws_own_order, ws_own_count, ws_part_mask, ws_part_keys, ws_own_recs, ws_own_seg, ws_own_items;
     // filtered coarse stage: sampled column tiles of the centroid matrix (stride coarse_s_stride; 0 = none yet),
     // candidate keys and counts
     DevBuf coarse_s, cnorm_s, ws_cand, ws_cnt;

@@ -83,6 +83,16 @@ void launch_coarse_select(const float* dist, int64_t nq, int nlist, int nprobe, 
 void launch_pq_tables(const float* x, int64_t nv, int d, const float* cent, int M, int ksub,
                       int dsub, const float* rnorm, int mode, float* out, hipStream_t s);
 
+// one visited probe of a query as the second build of the list-owned schedule reads it (scan16o.hip)
+struct OwnRec {
+    int32_t key;      // list id
+    uint32_t len;     // codes in the list
+    int64_t off;      // first code of the list
+    float dis0;       // coarse distance
+    uint32_t pos0;    // scan position of the list's first code (prefix over the query's probes in coarse order)
+};
+static_assert(sizeof(OwnRec) == 24, "OwnRec is copied as six dwords");
+
 struct ScanArgs {
     const uint8_t* codes;        // [ntotal][M] list-contiguous
     const int64_t* ids;          // [ntotal]
@@ -120,6 +130,10 @@ struct ScanArgs {
     unsigned long long* part_keys = nullptr; // [nq][8][k]
     const uint8_t* part_mask = nullptr;      // [nq] bit x: the query has a probe in partition x
     int qtab_scaled = 0;                     // qtab already holds (-2) * <q_m, cent_mj>
+    // second build (scan16o.hip): per-probe records grouped by partition [nq][nprobe], item entries [8][nq] = (query, first
+    // record | count << 16)
+    const OwnRec* own_recs = nullptr;
+    const uint2* own_items = nullptr;
     // float16 look-up tables (scan16h.hip): half(term2) [nlist][M*ksub] and half(-2 <q_m, cent_mj>) [nq][M*ksub]
     const uint16_t* term2h = nullptr;
     const uint16_t* qtabh = nullptr;
@@ -137,6 +151,13 @@ inline size_t owned_hist_ints(int nlist) { return (size_t)16 * nlist + 64; }
 void launch_qtab16(const float* queries, int64_t nq, const float* pq_cent_t, float* qtab, hipStream_t s);
 void launch_scan16_owned(const ScanArgs& a, hipStream_t s);
 void launch_owned_merge(const ScanArgs& a, hipStream_t s);
+// second build of the list-owned schedule (scan16o.hip): launch_owned2_prepare writes the per-probe records, the items of
+// every partition, own_count and part_mask (hist: [2][8][nlist] ints of scratch, minr [nq][8], seg [nq][8]);
+// launch_scan16_owned2 scans the items (nbuf = 1 / 2 table buffers); launch_owned_merge joins the parts as before
+bool scan16o_supports(const ScanArgs& a);
+void launch_owned2_prepare(const ScanArgs& a, const int* list_rank, int* hist, int* minr, uint32_t* seg, uint2* items,
+                           int* own_count, uint8_t* part_mask, OwnRec* recs, hipStream_t s);
+void launch_scan16_owned2(const ScanArgs& a, int nbuf, hipStream_t s);
 // same shape with float16 look-up tables (useFloat16LookupTables; scan16h.hip), k <= 256
 bool scan16h_supports(const ScanArgs& a);
 void launch_scan16h(const ScanArgs& a, hipStream_t s);
