@@ -409,7 +409,10 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         return fail(VLQ_ERR_UNSUPPORTED, "multi-index coarse quantizer without the precomputed table (type 2) is not built");
     const int64_t page = 32768;
     // M=16 x 8 bit x d=128 in table mode 1: the scan kernel builds the per-query table itself
-    const bool fused_tables = table_mode == 1 && h->M == 16 && h->ksub == 256 && h->dsub == 8;
+    // (and the 8 / 32 / 64-byte kernels of scanm.hip, any dsub, when they will serve the batch)
+    const bool scanm_shape = table_mode == 1 && (h->M == 8 || h->M == 32 || h->M == 64) && h->ksub == 256 &&
+                             h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN") && !getenv("VLQ_SCANM_QTAB");
+    const bool fused_tables = (table_mode == 1 && h->M == 16 && h->ksub == 256 && h->dsub == 8) || scanm_shape;
     if (table_mode != 0 && !fused_tables)
         TRY(h->ws_qtab.reserve((size_t)std::min(n, page) * E * sizeof(float)));
     for (int64_t i0 = 0; i0 < n; i0 += page) {
@@ -590,6 +593,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                     vlq::launch_scan16(a, h->stream);
                 }
             }
+            tm.stop();
+        } else if (vlq::scanm_supports(a) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
+            // 8 / 32 / 64-byte codes: the engineered organisation (scanm.hip); queries ordered like the 16-byte path
+            if (ni >= 1024 && h->nlist <= (1 << 22)) {
+                StageTimer tq(h, 1);
+                TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
+                TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
+                a.qorder = h->ws_qorder.as<int>();
+                tq.stop();
+            }
+            StageTimer tm(h, 2);
+            vlq::launch_scanm(a, h->stream);
             tm.stop();
         } else {
             StageTimer tm(h, 2);

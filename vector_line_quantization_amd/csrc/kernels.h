@@ -139,6 +139,10 @@ struct ScanArgs {
     const uint16_t* qtabh = nullptr;
 };
 void launch_scan(const ScanArgs& a, hipStream_t s);
+// 8-, 32- and 64-byte codes (M x 8 bit), table mode 1 / table type 2, per-query table in a.qtab: scan16's organisation over the
+// code size (scanm.hip); same results as launch_scan
+bool scanm_supports(const ScanArgs& a);
+void launch_scanm(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
 // list-owned schedule of the same kernel: launch_owned_order prepares own_order / own_count / part_mask,

@@ -1,0 +1,336 @@
+// List scan for 8-bit codes of 8, 32 and 64 bytes (M sub-quantizers x 256 centroids, precomputed-table mode 1 or 2): the
+// organisation of scan16_kernel (scan16.hip) over the code size.  The reference instantiates its scan per code size
+// (gpu/impl/IVFPQ.cu:149-172, PQScanMultiPassPrecomputed.cu:1299-1313, loads in PQCodeLoad.cuh:60-357); its CPU scan is one
+// loop over M (IndexIVFPQ.cpp:781-802).  Same arithmetic as the generic kernel in kernels.hip -- sim_table = term2[key] +
+// (-2) * sim_table_2 (fvec_madd, IndexIVFPQ.cpp:641-644), dis = dis0 + tab[0][c0] + ... + tab[M-1][c_{M-1}] strictly left to
+// right (:788-794) -- so results cannot depend on which kernel served a query; what changes is how the work is laid out:
+//   * probe metadata gathered once per query into LDS, walking order without dead probes (ProbeMeta, scan16_common.cuh);
+//   * the table has M x 256 entries = M KB: the workgroup grows with it (4 waves up to 16 bytes, 8 for 32, 16 for 64), so a
+//     thread always owns 16 table entries (8 for M = 8): the same register footprint for every size;
+//   * term2[key] and every lane's first code are requested one live probe ahead, the next chunk of a list before the current one
+//     is consumed; one workgroup barrier per probe with two table buffers (M <= 32), two with one (M = 64: 64 KB);
+//   * gathers in half blocks of 8 sub-quantizers: one SDWA op per code byte (byte extract and x4), sub-quantizer and buffer
+//     offsets in the ds_read offset field, two half blocks in flight while the previous one is added;
+//   * XCD-aware placement of the sorted query order, shared admission threshold of the workgroup's waves.
+#include <type_traits>
+
+#include "kernels.h"
+#include "scan_common.cuh"
+#include "scan16_common.cuh"
+#include "wave_topk.cuh"
+
+namespace vlq {
+
+// one half block of 8 sub-quantizers: words w0, w1 against table slices at LDS byte OFFS + 0 .. 7 KB (no wait)
+template <int OFFS>
+__device__ __forceinline__ void issue_hb(float (&v)[8], uint32_t w0, uint32_t w1, uint32_t two) {
+    VLQ_G8LO_NWI(OFFS, w0, w1);
+}
+template <int N>
+__device__ __forceinline__ void wait_hb(float (&v)[8]) {
+    if (N == 0) VLQ_WAIT8(0, v); else VLQ_WAIT8(8, v);
+}
+template <int M, int O, int S>
+__device__ __forceinline__ void adc_step(float (&hb)[M / 8][8], const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
+    constexpr int NH = M / 8;
+    wait_hb<(S == NH - 1) ? 0 : 8>(hb[S]);
+#pragma unroll
+    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hb[S][m]);
+    asm volatile("" : "+v"(dis));
+    if constexpr (S + 2 < NH) issue_hb<O + (S + 2) * 8192>(hb[S + 2], w[2 * (S + 2)], w[2 * (S + 2) + 1], two);
+    if constexpr (S + 1 < NH) adc_step<M, O, S + 1>(hb, w, dis, two);
+}
+
+// dis + the M table values of one code, left to right; the table sits at LDS byte offset O (compile time), w = the code's words.
+// Half blocks of 8 sub-quantizers (words 2h, 2h+1 against table slices 8h .. 8h+7): two in flight, the adds of one under the
+// reads of the next (lgkmcnt counts 16).
+template <int M, int O>
+__device__ __forceinline__ float adc_m(const uint32_t (&w)[M / 4], float dis, uint32_t two) {
+    constexpr int NH = M / 8;
+    static_assert(O + (NH - 1) * 8192 + 7168 < 65536, "ds_read offsets are 16 bits");
+    float hb[NH][8];
+    issue_hb<O>(hb[0], w[0], w[1], two);
+    if constexpr (NH > 1) issue_hb<O + 8192>(hb[1], w[2], w[3], two);
+    adc_step<M, O, 0>(hb, w, dis, two);
+    return dis;
+}
+
+template <int M> struct CodeWords { uint32_t w[M / 4]; };
+template <int M>
+__device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ base, int64_t row) {
+    CodeWords<M> c;
+    if (M == 8) {
+        const uint2 v = reinterpret_cast<const uint2*>(base)[row];
+        c.w[0] = v.x; c.w[1] = v.y;
+    } else {
+        const uint4* p = reinterpret_cast<const uint4*>(base) + row * (M / 16);
+#pragma unroll
+        for (int i = 0; i < M / 16; i++) {
+            const uint4 v = p[i];
+            c.w[4 * i] = v.x; c.w[4 * i + 1] = v.y; c.w[4 * i + 2] = v.z; c.w[4 * i + 3] = v.w;
+        }
+    }
+    return c;
+}
+
+template <int M> struct ScanMShape {
+    static constexpr int NW = M <= 16 ? 4 : M / 4;          // waves per workgroup
+    static constexpr int NT = 64 * NW;
+    static constexpr int E = M * 256;
+    static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8) or 4
+};
+
+template <int M, int KPL, int NBUF, bool IMI>
+__global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, int lut_region) {
+    constexpr int NW = ScanMShape<M>::NW, NT = ScanMShape<M>::NT, E = ScanMShape<M>::E, NI = ScanMShape<M>::NI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* lut = reinterpret_cast<float*>(smraw);                         // [NBUF][E] at LDS byte 0
+    u64* queue = reinterpret_cast<u64*>(smraw + lut_region);              // [NW][64]
+    ProbeMeta pm;
+    pm.carve(reinterpret_cast<unsigned char*>(queue + NW * 64), a.nprobe);
+    int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) + ProbeMeta::bytes(a.nprobe));
+    uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
+    uint32_t* wg_thr = reinterpret_cast<uint32_t*>(ord + ((a.nprobe + 1) & ~1));
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (__builtin_amdgcn_groupstaticsize() != 0) { *a.bad_key = 2; return; }    // adc_m addresses the buffers from LDS byte 0
+    uint32_t two = 2;
+    asm volatile("" : "+v"(two));
+    // XCD-aware placement (scan16.hip): XCD x serves the x-th contiguous chunk of the sorted query order; small batches split
+    // a query's probes over a.nsplit workgroups writing partial rows
+    int64_t q;
+    int part = 0;
+    {
+        const int64_t b = blockIdx.x;
+        const int64_t s = (b & 7) * a.xcd_chunk + (b >> 3);
+        if (s >= a.nq * a.nsplit) return;
+        const int64_t qs = s / a.nsplit;
+        part = (int)(s - qs * a.nsplit);
+        q = a.qorder ? a.qorder[qs] : qs;
+    }
+    const int64_t* kq = a.keys + q * a.nprobe;
+
+    const bool badkey = probe_meta_fill(a, q, pm, t, NT);
+    // -2 * sim_table_2 of the query, entries 4*(i*NT+t) .. +3: sub-quantizer NW*i + wave, centroids 4*lane .. +3
+    float4 m2t3[NI];
+    if (a.qtab) {                                   // materialised by launch_pq_tables
+        const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const float4 v = qt[i * NT + t];
+            m2t3[i] = make_float4(__fmul_rn(-2.f, v.x), __fmul_rn(-2.f, v.y), __fmul_rn(-2.f, v.z), __fmul_rn(-2.f, v.w));
+        }
+    } else {
+        // ProductQuantizer::compute_inner_prod_table (ProductQuantizer.cpp:424-436) in fvec_inner_product's order
+        // (utils.cpp:509-533: lane accumulator c % 4 takes component c in increasing order, the zero-padded tail and the
+        // unconditional + 0 of the last block, then (s0 + s1) + (s2 + s3)) from the transposed codebook [m][component][j]:
+        // the four centroids of a thread are one 16-byte load per component, a wave reads 1 KiB contiguous
+        // (one slice at a time, parked in the still unused table buffer: unrolled over the NI slices the 16 accumulators and
+        // their loads set the kernel's register count -- 131 instead of 100 VGPRs at M = 32, a workgroup less per CU)
+        const float* qv = a.queries + q * a.d;
+        const int dsub = a.dsub;
+#pragma unroll 1
+        for (int i = 0; i < NI; i++) {
+            const int m = NW * i + wave;
+            const float4* ct = reinterpret_cast<const float4*>(a.pq_cent_t + (size_t)m * dsub * 256) + lane;
+            const float* xm = qv + m * dsub;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+            auto madd = [](float4& s, float x, const float4 y) __attribute__((always_inline)) {
+                s.x = __fadd_rn(s.x, __fmul_rn(x, y.x)); s.y = __fadd_rn(s.y, __fmul_rn(x, y.y));
+                s.z = __fadd_rn(s.z, __fmul_rn(x, y.z)); s.w = __fadd_rn(s.w, __fmul_rn(x, y.w));
+            };
+            auto add0 = [](float4& s) __attribute__((always_inline)) {
+                s.x = __fadd_rn(s.x, 0.f); s.y = __fadd_rn(s.y, 0.f); s.z = __fadd_rn(s.z, 0.f); s.w = __fadd_rn(s.w, 0.f);
+            };
+            int c = 0;
+            for (; c + 4 <= dsub; c += 4) {
+                madd(s0, xm[c], ct[(c + 0) * 64]); madd(s1, xm[c + 1], ct[(c + 1) * 64]);
+                madd(s2, xm[c + 2], ct[(c + 2) * 64]); madd(s3, xm[c + 3], ct[(c + 3) * 64]);
+            }
+            const int r = dsub - c;
+            if (r > 0) madd(s0, xm[c], ct[c * 64]); else add0(s0);
+            if (r > 1) madd(s1, xm[c + 1], ct[(c + 1) * 64]); else add0(s1);
+            if (r > 2) madd(s2, xm[c + 2], ct[(c + 2) * 64]); else add0(s2);
+            add0(s3);
+            reinterpret_cast<float4*>(lut)[i * NT + t] =
+                make_float4(__fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0.x, s1.x), __fadd_rn(s2.x, s3.x))),
+                            __fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0.y, s1.y), __fadd_rn(s2.y, s3.y))),
+                            __fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0.z, s1.z), __fadd_rn(s2.z, s3.z))),
+                            __fmul_rn(-2.f, __fadd_rn(__fadd_rn(s0.w, s1.w), __fadd_rn(s2.w, s3.w))));
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) m2t3[i] = reinterpret_cast<const float4*>(lut)[i * NT + t];   // the thread's own stores
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int cut = probe_meta_scan(a, pm, lane);
+        __builtin_amdgcn_wave_barrier();
+        int nl = 0;
+        for (int p0 = 0; p0 < cut; p0 += 64) {      // coarse-distance order, dead probes dropped
+            const int p = p0 + lane;
+            const bool lv = p < cut && pm.pkey[p] >= 0;
+            const u64 mask = __ballot(lv);
+            if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
+            nl += __popcll(mask);
+        }
+        if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
+    }
+    __syncthreads();
+    const int nlive = misc[1];
+
+    WaveSelect<KPL, 1, (KPL >= 2)> sel;
+    sel.init(a.k, queue + wave * 64, lane);
+
+    float4 t2r[NI];
+    CodeWords<M> c0;
+#pragma unroll
+    for (int i = 0; i < M / 4; i++) c0.w[i] = 0;
+    uint32_t n_len = 0, n_pos0 = 0;
+    float n_dis0 = 0.f;
+    int64_t n_off = 0;
+    auto prefetch = [&](int i) __attribute__((always_inline)) {
+        if (i >= nlive) return;
+        const int p = ord[i];
+        const int64_t key = pm.pkey[p];
+        n_len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
+        n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
+        n_pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
+        {
+            const int64_t o = pm.poff[p];
+            n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
+                              __builtin_amdgcn_readfirstlane((uint32_t)o));
+        }
+        if (IMI) {
+            // table type 2 (IndexIVFPQ.cpp:645-686): sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of the
+            // coarse sub-index of its half
+            const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
+#pragma unroll
+            for (int i2 = 0; i2 < NI; i2++) {
+                const int64_t ki = (NW * i2 + wave) < M / 2 ? ki0 : ki1;
+                t2r[i2] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i2 * NT + t];
+            }
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)key * E);
+#pragma unroll
+            for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
+        }
+        c0 = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t, n_len - 1));
+    };
+    const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
+    prefetch(i_begin);
+    int buf = 0;
+    uint64_t nscan = 0;
+    for (int i = i_begin; i < i_end; i++) {
+        const uint32_t len = n_len, pos0 = n_pos0;
+        const float dis0 = n_dis0;
+        const int64_t off = n_off;
+        float* L = lut + buf * E;
+        if (NBUF == 1) __syncthreads();              // single table buffer: everyone is done scanning with it
+        __builtin_amdgcn_s_setprio(2);               // table build + the next list's first loads first (scan16.hip)
+#pragma unroll
+        for (int i2 = 0; i2 < NI; i2++) {
+            float4 sv;
+            sv.x = __fadd_rn(t2r[i2].x, m2t3[i2].x); sv.y = __fadd_rn(t2r[i2].y, m2t3[i2].y);
+            sv.z = __fadd_rn(t2r[i2].z, m2t3[i2].z); sv.w = __fadd_rn(t2r[i2].w, m2t3[i2].w);
+            reinterpret_cast<float4*>(L)[i2 * NT + t] = sv;
+        }
+        CodeWords<M> cc = c0;
+        prefetch(i + 1);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        if (sel.dirty) {
+            if (lane == 0) atomicMin(wg_thr, f32_to_ordered(sel.thr_own));
+            sel.dirty = false;
+        }
+        sel.refresh_with(*wg_thr);
+        auto scan_list = [&](auto bufc) {
+            constexpr int B = decltype(bufc)::value;
+            uint32_t j0 = (uint32_t)wave * 64;
+            if constexpr (M == 8) {
+                // 8-byte codes are one half block: two chunks per trip, the adds of the first under the reads of the second
+                // (what the half-block pipeline does inside a longer code)
+                for (; j0 + NT < len; j0 += 2 * NT) {
+                    const uint32_t ja = j0 + lane, jb = ja + NT;
+                    const CodeWords<M> cb = load_code<M>(a.codes, off + (int64_t)min(jb, len - 1));
+                    CodeWords<M> cn = cc;
+                    if (j0 + 2 * NT < len) cn = load_code<M>(a.codes, off + (int64_t)min(jb + NT, len - 1));
+                    float ha[8], hb2[8];
+                    issue_hb<B * E * 4>(ha, cc.w[0], cc.w[1], two);
+                    issue_hb<B * E * 4>(hb2, cb.w[0], cb.w[1], two);
+                    wait_hb<8>(ha);
+                    float da = dis0;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) da = __fadd_rn(da, ha[m]);
+                    asm volatile("" : "+v"(da));
+                    wait_hb<0>(hb2);
+                    float db = dis0;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) db = __fadd_rn(db, hb2[m]);
+                    sel.offer(da, pos0 + ja, true);
+                    sel.offer(db, pos0 + jb, jb < len);
+                    cc = cn;
+                }
+            }
+            for (; j0 < len; j0 += NT) {
+                const uint32_t j = j0 + lane;
+                CodeWords<M> cn = cc;
+                if (j0 + NT < len) cn = load_code<M>(a.codes, off + (int64_t)min(j + NT, len - 1));   // (wave-uniform)
+                const float dis = adc_m<M, B * E * 4>(cc.w, dis0, two);
+                sel.offer(dis, pos0 + j, j < len);
+                cc = cn;
+            }
+        };
+        if (NBUF == 1 || buf == 0) scan_list(std::integral_constant<int, 0>{});
+        else scan_list(std::integral_constant<int, NBUF == 2 ? 1 : 0>{});
+        nscan += len;
+        if (NBUF == 2) buf ^= 1;
+    }
+    merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
+                            [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
+    if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
+    if (badkey) *a.bad_key = 1;
+}
+
+template <int M, int KPL, int NBUF, bool IMI>
+static void launch_scanm_i(const ScanArgs& a, hipStream_t s) {
+    constexpr int NW = ScanMShape<M>::NW, E = ScanMShape<M>::E;
+    size_t lutb = (size_t)NBUF * E * 4;
+    const size_t merge = (size_t)NW * a.k * 8;
+    if (lutb < merge) lutb = merge;
+    const size_t tail = (size_t)NW * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+    const size_t smem = lutb + tail;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scanm_kernel<M, KPL, NBUF, IMI>), smem);
+    hipLaunchKernelGGL((scanm_kernel<M, KPL, NBUF, IMI>), dim3((unsigned)(8 * a.xcd_chunk)), dim3(64 * NW), smem, s, a, (int)lutb);
+}
+template <int M, int NBUF>
+static void launch_scanm_k(const ScanArgs& a, hipStream_t s) {
+#define VLQ_SM(K)                                                       \
+    do {                                                                \
+        if (a.imi_nbits > 0) launch_scanm_i<M, K, NBUF, true>(a, s);    \
+        else launch_scanm_i<M, K, NBUF, false>(a, s);                   \
+    } while (0)
+    if (a.k <= 64) VLQ_SM(1);
+    else if (a.k <= 128) VLQ_SM(2);
+    else if (a.k <= 256) VLQ_SM(4);
+    else VLQ_SM(16);
+#undef VLQ_SM
+}
+
+bool scanm_supports(const ScanArgs& a) {
+    return (a.M == 8 || a.M == 32 || a.M == 64) && a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
+           a.nprobe <= 1024 &&
+           (a.imi_nbits == 0 || a.M % 2 == 0);
+}
+
+void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
+    if (a_in.nq <= 0) return;
+    ScanArgs a = a_in;
+    if (a.nsplit < 1) a.nsplit = 1;
+    a.xcd_chunk = (int)((a.nq * a.nsplit + 7) / 8);
+    if (a.M == 8) launch_scanm_k<8, 2>(a, s);
+    else if (a.M == 32) launch_scanm_k<32, 2>(a, s);    // two 32 KB buffers end at byte 65535: the last gather offset still fits
+    else launch_scanm_k<64, 1>(a, s);
+}
+
+}  // namespace vlq
