@@ -119,7 +119,16 @@ struct ScanArgs {
     const int* qorder = nullptr; // optional processing order of the queries (scan16 only)
     int nsplit = 1;              // scan16: workgroups per query; > 1: D / I are [nsplit][nq][k] partial rows
     int long_lists = 0;          // scan16: mean list length >= 4 chunks -- selects the pipelined pair loop for k > 64 too
+    // scan16, split TAIL of a batch that fills the chip a fractional number of times (nsplit == 1): on every XCD the last
+    // tail_r queries of its chunk are scanned by tail_p workgroups each (contiguous ranges of the walking order, like
+    // nsplit) that write partial rows [tail_p][8 * tail_r][k] to tail_D / tail_I and their query to tail_rows; the whole
+    // queries in front of them write D / I directly.  launch_merge_topk(..., tail_rows) joins the parts.
+    int tail_r = 0, tail_p = 1;
+    float* tail_D = nullptr;
+    int64_t* tail_I = nullptr;
+    int* tail_rows = nullptr;    // [8 * tail_r], preset to -1
     int xcd_chunk = 0;           // set by the launcher
+    int grid_per_xcd = 0;        // set by the launcher: workgroups per XCD (xcd_chunk unless the tail is split)
     // list-owned schedule (scan16 only, DESIGN.md "list-owned schedule"): the lists are cut into 8
     // partitions of neighbouring lists, one per XCD; a workgroup serves the probes of ONE query that fall
     // into ONE partition and leaves its k best raw keys (ordered distance << 32 | scan position) in
@@ -185,7 +194,7 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
 
 // merge of per-shard results [nparts][nq][k] into the global top-k (list-sharded multi-GPU mode)
 void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,
-                       int64_t* I, hipStream_t s);
+                       int64_t* I, hipStream_t s, const int* row_map = nullptr);
 
 // out[i][0..dc) = x[i][col0 .. col0+dc)
 void launch_gather_cols(const float* x, int64_t n, int d, int col0, int dc, float* out, hipStream_t s);

@@ -1368,11 +1368,14 @@ template <int KPL>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ Dp,
                                                          const int64_t* __restrict__ Ip, int64_t nq,
                                                          int k, int nparts, float* __restrict__ D,
-                                                         int64_t* __restrict__ I) {
+                                                         int64_t* __restrict__ I, const int* __restrict__ row_map) {
     __shared__ u64 queue[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= nq) return;
+    // row_map (the split tail of a batch, scan16.hip): partial row q belongs to output row row_map[q]; -1: unused slot
+    const int64_t orow = row_map ? (int64_t)row_map[q] : q;
+    if (orow < 0) return;
     WaveSelect<KPL> sel;
     sel.init(k, queue[wave], lane);
     const int num = nparts * k;
@@ -1403,19 +1406,19 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
             dis = Dp[src];
             id = Ip[src];
         }
-        D[q * k + e] = dis;
-        I[q * k + e] = id;
+        D[orow * k + e] = dis;
+        I[orow * k + e] = id;
     }
 }
 
 void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,
-                       int64_t* I, hipStream_t s) {
+                       int64_t* I, hipStream_t s, const int* row_map) {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 3) / 4)), block(256);
-    if (k <= 64) hipLaunchKernelGGL(merge_topk_kernel<1>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
-    else if (k <= 256) hipLaunchKernelGGL(merge_topk_kernel<4>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
-    else if (k <= 512) hipLaunchKernelGGL(merge_topk_kernel<8>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
-    else hipLaunchKernelGGL(merge_topk_kernel<16>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I);
+    if (k <= 64) hipLaunchKernelGGL(merge_topk_kernel<1>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I, row_map);
+    else if (k <= 256) hipLaunchKernelGGL(merge_topk_kernel<4>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I, row_map);
+    else if (k <= 512) hipLaunchKernelGGL(merge_topk_kernel<8>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I, row_map);
+    else hipLaunchKernelGGL(merge_topk_kernel<16>, grid, block, 0, s, Dp, Ip, nq, k, nparts, D, I, row_map);
 }
 
 __global__ void gather_cols_kernel(const float* __restrict__ x, int64_t n, int d, int col0, int dc,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
     // small batches: a query's probes are split over a.nsplit workgroups (parts = contiguous ranges
     // of the walking order) that write partial top-k rows [part][nq][k]; merge_topk_kernel joins them
     int64_t q;
-    int part = 0, own_x = 0;
+    int part = 0, own_x = 0, nparts = 1, tail_slot = -1;
     if (OWNED) {
         // consecutive workgroups go round-robin over the 8 XCDs: XCD x serves partition x, its items in
         // the order launch_owned_order gave them (neighbouring lists next to each other in time)
@@ -60,12 +60,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         const int64_t slot = b >> 3;
         if (slot >= a.own_count[own_x]) return;
         q = a.own_order[(int64_t)own_x * a.nq + slot];
+    } else if (a.tail_r > 0) {
+        // split tail (kernels.h): XCD x owns the sorted positions [x * chunk, (x + 1) * chunk) /\ [0, nq); the first of them
+        // whole, one workgroup each, the last tail_r in tail_p parts -- dispatched after the whole ones, they fill the
+        // slots of the batch's last, partial round with short workgroups instead of leaving most of the chip idle
+        const int64_t b = blockIdx.x;
+        const int x = (int)(b & 7);
+        const int64_t l = b >> 3;
+        const int64_t first = (int64_t)x * a.xcd_chunk;
+        const int64_t nx = max((int64_t)0, min((int64_t)a.xcd_chunk, a.nq - first));
+        const int64_t tx = min((int64_t)a.tail_r, nx), wx = nx - tx;
+        int64_t qs;
+        if (l < wx) {
+            qs = first + l;
+        } else {
+            const int64_t l2 = l - wx;
+            if (l2 >= tx * a.tail_p) return;
+            const int64_t ti = l2 / a.tail_p;
+            part = (int)(l2 - ti * a.tail_p);
+            nparts = a.tail_p;
+            qs = first + wx + ti;
+            tail_slot = (int)((int64_t)x * a.tail_r + ti);
+        }
+        q = a.qorder ? a.qorder[qs] : qs;
+        if (tail_slot >= 0 && part == 0 && threadIdx.x == 0) a.tail_rows[tail_slot] = (int)q;
     } else {
         const int64_t b = blockIdx.x;
         const int64_t s = (b & 7) * a.xcd_chunk + (b >> 3);
         if (s >= a.nq * a.nsplit) return;
         const int64_t qs = s / a.nsplit;
         part = (int)(s - qs * a.nsplit);
+        nparts = a.nsplit;
         q = a.qorder ? a.qorder[qs] : qs;
     }
     const int64_t* kq = a.keys + q * a.nprobe;
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
             c1 = cpn[min((uint32_t)t + NT, last)];
         }
     };
-    const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
+    const int i_begin = (int)((int64_t)part * nlive / nparts), i_end = (int)((int64_t)(part + 1) * nlive / nparts);
     prefetch(i_begin);
     int buf = 0;
     uint64_t nscan = 0;
@@ -230,6 +255,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
                 if (e < a.k) out[e] = sel.best[r];
             }
         }
+    } else if (tail_slot >= 0) {
+        ScanArgs em = a;             // partial rows of a split tail query: [part][8 * tail_r][k]
+        em.D = a.tail_D;
+        em.I = a.tail_I;
+        merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, em, (int64_t)part * 8 * a.tail_r + tail_slot, wave, lane,
+                                    [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     } else {
         merge_and_emit<KPL, NW, QR>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                                     [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
@@ -531,7 +562,7 @@ void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
 template <int KPL, int NW, int NBUF, bool PIPE, bool IMI>
 static void launch_scan16_i(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE, IMI>), smem);
-    const unsigned grid = (unsigned)(8 * a.xcd_chunk);
+    const unsigned grid = (unsigned)(8 * a.grid_per_xcd);
     hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE, IMI>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
 template <int KPL, int NW, int NBUF, bool PIPE>
@@ -553,6 +584,12 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     ScanArgs a = a_in;
     if (a.nsplit < 1 || a.part_keys) a.nsplit = 1;
     a.xcd_chunk = (int)((a.nq * a.nsplit + 7) / 8);
+    if (a.nsplit > 1 || a.part_keys || !a.tail_D) a.tail_r = 0;
+    a.grid_per_xcd = a.xcd_chunk;
+    if (a.tail_r > 0) {              // per XCD: its whole queries, then tail_p workgroups for each of its last tail_r
+        if (a.tail_r > a.xcd_chunk) a.tail_r = a.xcd_chunk;
+        a.grid_per_xcd = a.xcd_chunk - a.tail_r + a.tail_r * a.tail_p;
+    }
     // k <= 64: 8 waves per workgroup share one LUT (32 waves per CU at 4 workgroups);
     // larger k keeps more selection state per wave, so stay at 4 waves
     // Measured alternatives (r01, MI355X, bench data): 8 waves per workgroup 0.95 ms, single
