@@ -246,7 +246,18 @@ class GpuIndexIVFPQ : public GpuIndex {
       VLQ_CHECK(vlq_ivfpq_search_preassigned(h_, n, x, keys.data(), cd.data(), nprobe_, (int)k, distances,
                                              (int64_t*)labels, 1));
     } else {
-      VLQ_CHECK(vlq_ivfpq_search(h_, n, x, nprobe_, (int)k, distances, (int64_t*)labels));
+      int rc = vlq_ivfpq_search(h_, n, x, nprobe_, (int)k, distances, (int64_t*)labels);
+      if (rc == VLQ_ERR_UNSUPPORTED && fp16TablesOn_) {
+        // useFloat16LookupTables is a speed hint of the reference (its drivers pass co.useFloat16 unconditionally): data whose
+        // table entries leave the half range (byte-valued descriptors: term 2 reaches 1e5) are searched with fp32 tables
+        // instead of failing the caller's search()
+        fprintf(stderr, "WARNING GpuIndexIVFPQ: float16 look-up tables cannot hold this index's table entries (%s); "
+                        "using fp32 tables\n", vlq_last_error());
+        VLQ_CHECK(vlq_ivfpq_set_float16_tables(h_, 0));
+        fp16TablesOn_ = false;
+        rc = vlq_ivfpq_search(h_, n, x, nprobe_, (int)k, distances, (int64_t*)labels);
+      }
+      if (rc != VLQ_OK) { FAISS_THROW_FMT("vlq_ivfpq_search -> %d: %s", rc, vlq_last_error()); }
     }
   }
 
@@ -468,9 +479,10 @@ class GpuIndexIVFPQ : public GpuIndex {
   // (gpu/test/deep1b16_query.cpp:239-243: co.useFloat16 = true -> config.useFloat16LookupTables), a
   // speed/memory option of its CUDA kernels (gpu/GpuIndexIVFPQ.h:24-38, impl/IVFPQ.cu:1442 toHalf).
   // They are ACCEPTED: the VLQ search (the drivers' path) builds float16 tables the way the reference
-  // does (vlq_line_set_float16_tables); the plain IVFPQ path and the coarse quantizer compute the same
-  // quantities in fp32 -- every result the fp16 configuration could return is returned at higher
-  // precision, and fp32 is the path pinned bit for bit to the CPU index.  Only options that would
+  // does (vlq_line_set_float16_tables), and so does the plain IVFPQ search for 16 x 8-bit codes with precomputed
+  // tables (vlq_ivfpq_set_float16_tables; data that leave the half range fall back to fp32 tables with a warning);
+  // other shapes and the coarse quantizer compute the same quantities in fp32 -- every result the fp16
+  // configuration could return is returned at higher precision, and fp32 is the path pinned bit for bit to the CPU index.  Only options that would
   // change SEMANTICS are rejected.
   void verifyConfig_() const {
     FAISS_THROW_IF_NOT_MSG(ivfpqConfig_.memorySpace == MemorySpace::Device || ivfpqConfig_.memorySpace == MemorySpace::Unified,
@@ -485,13 +497,16 @@ class GpuIndexIVFPQ : public GpuIndex {
     VLQ_CHECK(vlq_ivfpq_set_search_options(h_, 1, usePrecomputed_ ? 1 : 0, 0));
     // useFloat16LookupTables: half tables for 16 x 8-bit codes with precomputed tables, built as the reference
     // builds them (vlq_ivfpq_set_float16_tables); other shapes compute in fp32 (superset precision)
-    if (ivfpqConfig_.useFloat16LookupTables && subQuantizers_ == 16 && bitsPerCode_ == 8)
+    if (ivfpqConfig_.useFloat16LookupTables && subQuantizers_ == 16 && bitsPerCode_ == 8) {
       VLQ_CHECK(vlq_ivfpq_set_float16_tables(h_, 1));
+      fp16TablesOn_ = true;
+    }
   }
   GpuIndexIVFPQConfig ivfpqConfig_;
   int nlist_, nprobe_, subQuantizers_, bitsPerCode_;
   size_t reserveMemoryVecs_;
   bool usePrecomputed_ = false;
+  mutable bool fp16TablesOn_ = false;   ///< half tables in use for the plain IVFPQ search (dropped if the data do not fit the half range)
   std::vector<float> coarse_, pqCentroids_;
   std::vector<int> edgeInfoV_;
   std::vector<float> edgeDistInfoV_, lambdaInfoV_;

@@ -49,6 +49,10 @@ struct State {
     uint64_t cent_sig = 0;      // signature of the trained state on the device
     uint64_t list_sig = 0;      // signature of the lists on the device
     bool lists_dirty = true;
+    // shape the handle was created for: an index deleted and another one allocated at the same address (index_factory
+    // loops, autotune) must not inherit a handle of another shape
+    int d = 0, M = 0, nbits = 0;
+    size_t nlist = 0;
 };
 
 std::mutex mu;
@@ -65,6 +69,8 @@ void check(int rc, const char* what) {
 }
 
 void report() {
+    for (auto& kv : states)            // the handles' device memory goes back before the process ends
+        if (kv.second.h) { vlq_ivfpq_destroy(kv.second.h); kv.second.h = nullptr; }
     fprintf(stderr,
             "[vlq-interpose] device searches=%llu queries=%llu ncode=%llu adds=%llu vectors=%llu tables=%llu "
             "list_uploads=%llu cpu_fallbacks=%llu\n",
@@ -105,12 +111,17 @@ bool device_shape(const faiss::IndexIVFPQ* ix) {
 // device handle of `ix` with its trained state (centroids, codebook, search options) current
 State& sync(const faiss::IndexIVFPQ* ix, bool with_lists) {
     State& st = states[ix];
+    if (st.h && (st.d != ix->d || st.nlist != ix->nlist || st.M != (int)ix->pq.M || st.nbits != (int)ix->pq.nbits)) {
+        vlq_ivfpq_destroy(st.h);       // another index lives at this address now
+        st = State();
+    }
     if (!st.h) {
         const char* dev = getenv("VLQ_DEVICE");
         check(vlq_ivfpq_create(&st.h, dev ? atoi(dev) : 0, ix->d, (int)ix->nlist, (int)ix->pq.M, (int)ix->pq.nbits),
               "vlq_ivfpq_create");
         st.cent_sig = 0;
         st.lists_dirty = true;
+        st.d = ix->d; st.nlist = ix->nlist; st.M = (int)ix->pq.M; st.nbits = (int)ix->pq.nbits;
     }
     const faiss::IndexFlat* fl = flat_l2(ix);
     const faiss::MultiIndexQuantizer* mi = imi2(ix);

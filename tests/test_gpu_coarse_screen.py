@@ -104,6 +104,27 @@ def test_queries_outside_the_half_range_and_nan_rows():
     assert np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(keys1, keys0)
 
 
+@pytest.mark.parametrize("nlist,d,nprobe", [(1024, 32, 8), (4096, 128, 32), (16384, 64, 32)])
+@pytest.mark.parametrize("far", [1.5, 2.0, 3.0, 4.0, 8.0])
+def test_outlier_queries_near_the_half_overflow(nlist, d, nprobe, far):
+    """Queries at 1.5 ... 8 times the centroid cloud's radius from its centre: their stored half distances reach the top
+    of the half range, where a value that rounds to +inf can never pass `w <= T`.  A bound at or above 65504 in the stored
+    domain must send the row to the exact path (screen_threshold's tmax): keys and distances equal the oracle's."""
+    rng = np.random.default_rng(int(nlist + d + 10 * far))
+    g, ox, cent = make(nlist, d, rng)
+    mu = cent.mean(0)
+    radius = np.sqrt(((cent - mu) ** 2).sum(1)).max()
+    dirs = rng.standard_normal((NQ, d)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    scale = (far * (0.8 + 0.4 * rng.random((NQ, 1)))).astype(np.float32)
+    xq = (mu + dirs * radius * scale).astype(np.float32)
+    xq[:200] = rng.random((200, d)).astype(np.float32)            # ordinary rows among them
+    cd, keys = g.coarse_search(xq, nprobe)
+    cdo, keyso = ox.coarse_search(xq, nprobe, canonical=True)
+    assert np.array_equal(bits(cd), bits(cdo))
+    assert np.array_equal(keys, keyso)
+
+
 @pytest.mark.parametrize("nbits,d,nprobe", [(8, 128, 16), (10, 64, 64)])
 def test_multi_index_halves_go_through_the_screen(nbits, d, nprobe):
     """Inverted multi-index: each half's table of 2^nbits sub-centroids is screened like a flat quantizer's; the walk over

@@ -757,13 +757,18 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
                       &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
-                      &h->imi_norm, &h->imi_virtual, &h->ws_imi};
+                      &h->imi_norm, &h->imi_virtual, &h->ws_imi,
+                      // the float16 screen of the coarse stage: built for every index at set_coarse_centroids
+                      &h->screen.half, &h->screen.mu, &h->screen.norm_c, &h->imi_screen[0].half, &h->imi_screen[0].mu,
+                      &h->imi_screen[0].norm_c, &h->imi_screen[1].half, &h->imi_screen[1].mu, &h->imi_screen[1].norm_c,
+                      &h->ws_qn_c, &h->ws_xh, &h->ws_xflags, &h->ws_screen_cnt};
     for (auto b : bufs) b->release();
     if (h->screen_cnt_host) (void)hipHostFree(h->screen_cnt_host);
     if (h->ws_kept.p) {
         unsigned long long kept = 0;
         (void)hipMemcpy(&kept, h->ws_kept.p, 8, hipMemcpyDeviceToHost);
         fprintf(stderr, "[vlq] coarse screen: %llu columns kept in total\n", kept);
+        h->ws_kept.release();
     }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;

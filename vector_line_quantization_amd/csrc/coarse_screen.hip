@@ -268,8 +268,12 @@ __device__ __forceinline__ uint32_t wave_min_ordered(float v) {
 
 // T: the largest stored value (half(sd * approximate distance), read back as float) a column of this row may have and still
 // be kept, from the row's cut (nprobe-th smallest stored lane minimum); *finite = the bound is a number
+// tmax: the largest stored value that is still a number -- 65504 where the stored values are halves.  A bound at or above
+// it could admit columns whose stored value overflowed to +inf (sd * distance >= 65520: queries far outside the centroid
+// cloud, for which sd was not chosen), and `w <= T` never holds for +inf: such a row is not decided here (*finite = false ->
+// the exact path).
 __device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float qn0v, float cmax, float cmax0, float c_sub, float inv_sd,
-                                                  bool* finite) {
+                                                  bool* finite, float tmax = FLT_MAX_F) {
     // delta(q), inflated: every factor rounded up generously (the bound is what exactness rests on)
     // (qn / cmax: centred -- the half arithmetic's error; qn0 / cmax0: as given -- the exact stage's own fp32 error)
     const float qnorm = __fmul_rn(sqrtf(fmaxf(qnv, 0.f)), 1.0001f);
@@ -290,7 +294,7 @@ __device__ __forceinline__ float screen_threshold(float cut_s, float qnv, float 
     const float tx = ts >= 0.f ? __fmul_rn(ts, 1.00049f /* > 1 / (1 - eps) */) : __fmul_rn(ts, 0.99951f /* < 1 / (1 + eps): towards 0 */);
     // back to the stored domain, rounded up (1 / inv_sd is the power of two sd: exact)
     const float T = __fmul_rn(__fadd_rn(tx, __fmul_rn(1e-6f, fabsf(tx))), 1.f / inv_sd);
-    *finite = thr < FLT_MAX_F && T < FLT_MAX_F;
+    *finite = thr < FLT_MAX_F && T < tmax;
     return T;
 }
 
@@ -325,8 +329,8 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_kernel(const _Float16*
     }
     const float cut_s = screen_cut<MT>(mt, nprobe, lane);      // scaled by sd, rounded to half
     bool finite;
-    const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
-    const bool undecided = !finite || flags[q];       // NaN / infinite bound, or a query outside the half range
+    const float T = screen_threshold(cut_s, qnv, qn0[q], cmax, cmax0, c_sub, inv_sd, &finite, 65504.f);
+    const bool undecided = !finite || flags[q];       // NaN / infinite / half-overflowing bound, or a query outside the half range
     // kept columns: a ballot per register component (most are empty: ~nprobe + 20 of the row's elements pass)
     uint32_t* out = keep + q * kKeepCap;
     int total = 0;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Fl
     }
     const float cut_s = screen_cut<MT>(mt, nprobe, lane);
     bool finite;
-    const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite);
+    const float T = screen_threshold(cut_s, qn[q], qn0[q], cmax, cmax0, c_sub, inv_sd, &finite, 65504.f);
     const bool undecided = !finite || flags[q];
     int npass = 0;
     for (int t0 = 0; t0 < ntile; t0 += 64) {
