@@ -44,7 +44,7 @@ def test_interposer_exports_the_reference_symbols():
     for s in ("_ZNK5faiss10IndexIVFPQ19search_knn_with_keyEmPKfPKlS2_PNS_9HeapArrayINS_4CMaxIflEEEEb",
               "_ZN5faiss10IndexIVFPQ10add_core_oElPKfPKlPfS4_", "_ZN5faiss10IndexIVFPQ16precompute_tableEv"):
         assert s in syms, s
-    for exe in ("demo_sift1M", "sift1b_imi_pq"):
+    for exe in ("demo_sift1M", "sift1b_imi_pq", "deep1b_imi_pq", "deep1b16_imi_pq"):
         assert os.access(os.path.join(RD, exe), os.X_OK)
 
 
@@ -120,6 +120,47 @@ def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
     assert len(rc) == 3 and len(dc) == 10 and len(dd) == 10
     for a, b in zip(dc, dd):
         assert len(a) == len(b) == 10
+        assert max(abs(float(x) - float(y)) / max(1e-9, abs(float(x))) for x, y in zip(a, b)) <= 1e-4
+    assert all(len(set(a) & set(b)) >= 9 for a, b in zip(ic, idd))
+    assert max(abs(a - b) for a, b in zip(rc, rd)) <= 0.004
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["deep1b_imi_pq", "deep1b16_imi_pq"])
+def test_deep1b_drivers_unchanged_on_the_device(tmp_path, driver):
+    """tests/deep1b_imi_pq.cpp and tests/deep1b16_imi_pq.cpp as shipped (BASELINE configs[3] / [4] name them: 96 dimensions,
+    inverted multi-index 2 x 14 bits = 2^28 lists, 8- / 16-byte codes, nprobe 2048, k 128), compiled in place: CPU-only run,
+    then the device run of the SAME binary on the cached populated index the first run wrote; 8-byte codes are served by
+    scanm_kernel<8, ..., IMI>, 16-byte codes by scan16's table type 2.  Heavy like the sift1b driver (2^28 lists: 4.3 GB
+    index files): opt-in with VLQ_RUN_DEEP1B_DRIVERS=1; the run of record is profiles/r04_reference_drivers.txt."""
+    if os.environ.get("VLQ_RUN_DEEP1B_DRIVERS") != "1":
+        pytest.skip("opt-in: VLQ_RUN_DEEP1B_DRIVERS=1")
+    exe = os.path.join(RD, driver)
+    if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
+        pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
+    data, run = str(tmp_path / "data"), str(tmp_path / "run")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "deep1b", run, "500000", "1000"])
+    outs = {}
+    for mode in ("off", "on"):
+        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
+                           timeout=1100, cwd=run)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[mode] = (p.stdout, p.stderr)
+        print(driver, mode, "\n".join(p.stdout.splitlines()[-6:]), p.stderr.splitlines()[-1])
+
+    def parse(out):
+        rec = [float(v) for v in re.findall(r"R@(?:1|10|100) = ([0-9.]+)", out)[-3:]]
+        ids = [tuple(int(v) for v in ln.split(":", 1)[1].split()) for ln in out.splitlines() if re.match(r"query\s+\d+:", ln)]
+        dis = [tuple(ln.split(":", 1)[1].split()) for ln in out.splitlines() if ln.strip().startswith("dis:")]
+        return rec, ids, dis
+    rc, ic, dc = parse(outs["off"][0])
+    rd, idd, dd = parse(outs["on"][0])
+    summ = re.search(r"\[vlq-interpose\] device searches=(\d+) queries=(\d+) ncode=(\d+) .*cpu_fallbacks=(\d+)", outs["on"][1])
+    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 1000 and int(summ.group(3)) > 0 and int(summ.group(4)) == 0
+    # sub-vectors of 12 / 6 dimensions: the reference's PQ tables take its SSE path (no BLAS), the coarse stage runs in the
+    # reference's own code in both runs -- distances to the north star's 1e-4, the same neighbours up to near-ties
+    assert len(rc) == 3 and len(dc) == 10 and len(dd) == 10
+    for a, b in zip(dc, dd):
         assert max(abs(float(x) - float(y)) / max(1e-9, abs(float(x))) for x, y in zip(a, b)) <= 1e-4
     assert all(len(set(a) & set(b)) >= 9 for a, b in zip(ic, idd))
     assert max(abs(a - b) for a, b in zip(rc, rd)) <= 0.004

@@ -5,6 +5,7 @@ real-valued noise (no exact distance ties, so CPU and device runs pick the same 
 truth by brute force.  The drivers' hard-coded /home/data prefix is redirected to <root> by the interposer
 (VLQ_DATA_ROOT).      python tools/make_driver_data.py <root> [nt nb nq]
                       python tools/make_driver_data.py <root> sift1b <cwd> [nb nq]
+                      python tools/make_driver_data.py <root> deep1b <cwd> [nb nq]   (tests/deep1b_imi_pq.cpp, deep1b16_imi_pq.cpp)
 The second form prepares tests/sift1b_imi_pq.cpp: byte-valued base.umem / query.umem / learn.umem ("num dim" text
 header, data from byte 20, :100-150), gnd/idx_1000M.ivecs, and -- in <cwd>, where the driver looks for its cache
 (:225-243) -- sift1b_14_8_trained_index.faissindex in the reference's file format (index_io.cpp:226-317): the
@@ -129,10 +130,66 @@ def sift1b(root, cwd, nb=500000, nq=1000):
     print("wrote %s/sift1b (base %d, query %d, ground truth %d) and %s/sift1b_14_8_trained_index.faissindex" % (root, nb, nq, kgt, cwd))
 
 
+def mem_write(path, x, dtype):
+    """the fork's .umem / .imem container (filehelper.cpp:253-342): the text "<num> <dim>" in the first 20 bytes, rows behind"""
+    n, d = x.shape
+    with open(path, "wb") as f:
+        f.write(("%d %d\n" % (n, d)).encode().ljust(20, b" "))
+        np.ascontiguousarray(x, dtype).tofile(f)
+
+
+def deep1b(root, cwd, nb=500000, nq=1000):
+    """tests/deep1b_imi_pq.cpp and tests/deep1b16_imi_pq.cpp (BASELINE configs[3] / [4] name them): float rows of 96
+    dimensions in deep1B/{learn,base,query}.umem, ground truth in deep1B/truth.imem, and in <cwd> the trained-index caches
+    both drivers look for (:246-256): deep1b_14_8_ / deep1b_14_16_trained_index.faissindex (multi-index 2 x 14 bits over
+    48-dimensional halves, 8 / 16 PQ bytes)."""
+    d, nc, sigma, rank, spread, kgt = 96, 2000, 0.005, 12, 0.4, 100
+    centres = np.random.default_rng(1).random((nc, d)).astype(np.float32)
+    sub = (np.random.default_rng(2).standard_normal((rank, d)) / np.sqrt(rank)).astype(np.float32)
+
+    def gen(seed, n):
+        r = np.random.default_rng(seed)
+        x = centres[r.integers(0, nc, n)] + sigma * r.standard_normal((n, d)) + spread * r.standard_normal((n, rank)) @ sub
+        return (x - 0.5).astype(np.float32)
+
+    os.makedirs(os.path.join(root, "deep1B"), exist_ok=True)
+    os.makedirs(cwd, exist_ok=True)
+    xb, xq = gen(22, nb), gen(33, nq)
+    mem_write(os.path.join(root, "deep1B", "base.umem"), xb, np.float32)
+    mem_write(os.path.join(root, "deep1B", "query.umem"), xq, np.float32)
+    mem_write(os.path.join(root, "deep1B", "learn.umem"), gen(11, 1000), np.float32)   # read, never used: the index is cached
+    xbf, xqf = xb.astype(np.float64), xq.astype(np.float64)
+    bn = (xbf ** 2).sum(1)
+    gt = np.empty((nq, kgt), np.int32)
+    for i in range(0, nq, 256):
+        dist = bn[None, :] - 2.0 * xqf[i:i + 256] @ xbf.T
+        idx = np.argpartition(dist, kgt, axis=1)[:, :kgt]
+        o = np.argsort(np.take_along_axis(dist, idx, 1), axis=1, kind="stable")
+        gt[i:i + 256] = np.take_along_axis(idx, o, 1)
+    mem_write(os.path.join(root, "deep1B", "truth.imem"), gt, np.int32)
+    r = np.random.default_rng(5)
+    nbits, kc, hd = 14, 1 << 14, d // 2
+    tr = gen(44, 60000)
+    imi = np.stack([tr[r.permutation(tr.shape[0])[:kc], h * hd:(h + 1) * hd] for h in range(2)])
+    imi = (imi + 0.002 * r.standard_normal(imi.shape)).astype(np.float32)
+    res = np.empty_like(tr[:20000])
+    for h in range(2):
+        sl = slice(h * hd, (h + 1) * hd)
+        a = (((imi[h] ** 2).sum(1))[None, :] - 2.0 * tr[:20000, sl] @ imi[h].T).argmin(1)
+        res[:, sl] = tr[:20000, sl] - imi[h][a]
+    for M in (8, 16):
+        ds = d // M
+        pq = np.stack([res[r.permutation(20000)[:256], m * ds:(m + 1) * ds] for m in range(M)]).astype(np.float32)
+        write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_trained_index.faissindex" % M), d, nbits, imi, M, pq)
+    print("wrote %s/deep1B (base %d, query %d, ground truth %d) and %s/deep1b_14_{8,16}_trained_index.faissindex" % (root, nb, nq, kgt, cwd))
+
+
 def main():
     root = sys.argv[1]
     if len(sys.argv) > 2 and sys.argv[2] == "sift1b":
         return sift1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:6]))
+    if len(sys.argv) > 2 and sys.argv[2] == "deep1b":
+        return deep1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:6]))
     nt, nb, nq = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (40000, 200000, 1000)
     # low intrinsic dimension (what makes real descriptors rankable by short codes, bench.py's second data set):
     # most of a point's offset from its centre lies in one fixed 12-dimensional subspace
