@@ -36,6 +36,12 @@ void launch_line_select(const float* dist, int64_t nq, int nlist, const int64_t*
                         const int64_t* line_off = nullptr, const int64_t* line_len = nullptr,
                         int max_line_codes = 0, LineMeta* sel_meta = nullptr, int32_t* sel_cnt = nullptr);
 
+// the same selection and outputs by one workgroup per query (line_select2.hip): radix threshold + one sort of the winners
+bool line_select2_supports(int nprobe, int nedge, int w1);
+void launch_line_select2(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe, const int32_t* edge_info,
+                         const float* edge_dist, int nedge, int w1, int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s,
+                         const int64_t* line_off, const int64_t* line_len, int max_line_codes, LineMeta* sel_meta, int32_t* sel_cnt);
+
 struct LineScanArgs {
     const uint8_t* codes;        // [ntotal][M] line-contiguous
     const uint8_t* lambdas;      // [ntotal]

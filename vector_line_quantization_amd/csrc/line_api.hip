@@ -445,10 +445,6 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
     for (int64_t i0 = 0; i0 < n; i0 += page) {
         const int64_t ni = std::min(page, n - i0);
         const float* xi = (const float*)xd + i0 * b->d;
-        // 1. all centroid "distances" without |q|^2 + the nprobe nearest (Distance.cu:233-383)
-        TRY(coarse_page(b, ni, xi, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false, true));
-        // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
-        int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
         // compact records (16-byte scan kernel): their sort key holds the candidate index in 24 bits
         const bool small_tables = (b->M & 3) == 0 && b->M <= 32 && b->M * b->ksub <= 2048;
         const bool with_meta = ((b->M == 16 && b->ksub == 256) || small_tables) && (int64_t)nprobe * h->nedge < (int64_t(1) << 24);
@@ -458,11 +454,31 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
             vlq::launch_to_half(b->term2.as<float>(), (int64_t)b->nlist * (int64_t)E, 1.f, h->term2h.as<uint16_t>(), b->stream);
             h->term2h_valid = true;
         }
-        vlq::launch_line_select(b->ws_dist.as<float>(), ni, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
-                                h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
-                                sel_line, h->ws_sel_b2.as<float>(), h->ws_sel_g.as<float>(), b->stream,
-                                h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
-                                with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() : nullptr, h->ws_sel_cnt.as<int32_t>());
+        int32_t* sel_line = h->ws_sel_line.as<int32_t>() + i0 * w1;
+        // (Steps 1 and 2 in sub-pages whose distance matrix stays in the 256 MB Infinity Cache between the kernel that writes
+        // it and the line select that gathers from it were measured and lose: 2000 queries in pages of 500 / 1000 queries 3.22 /
+        // 3.06 ms against 2.98 for one page -- the smaller launches cost more than the cache returns.)
+        const int64_t sub = ni;
+        static const bool ls_old = getenv("VLQ_LINE_SELECT_WAVE") != nullptr;     // A/B: the one-wave-per-query kernel
+        for (int64_t j0 = 0; j0 < ni; j0 += sub) {
+            const int64_t nj = std::min(sub, ni - j0);
+            // 1. all centroid "distances" without |q|^2 + the nprobe nearest (Distance.cu:233-383)
+            TRY(coarse_page(b, nj, xi + j0 * b->d, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>(), true, false, true));
+            // 2. the w1 best lines among nprobe x nedge (BroadcastSum.cu:477-560)
+            vlq::LineMeta* metaj = with_meta ? h->ws_sel_meta.as<vlq::LineMeta>() + j0 * w1 : nullptr;
+            if (!ls_old && vlq::line_select2_supports(nprobe, h->nedge, w1))
+                vlq::launch_line_select2(b->ws_dist.as<float>(), nj, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
+                                         h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
+                                         sel_line + j0 * w1, h->ws_sel_b2.as<float>() + j0 * w1, h->ws_sel_g.as<float>() + j0 * w1,
+                                         b->stream, h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
+                                         metaj, h->ws_sel_cnt.as<int32_t>() + j0);
+            else
+                vlq::launch_line_select(b->ws_dist.as<float>(), nj, b->nlist, h->ws_keys.as<int64_t>(), nprobe,
+                                        h->edge_info.as<int32_t>(), h->edge_dist.as<float>(), h->nedge, w1,
+                                        sel_line + j0 * w1, h->ws_sel_b2.as<float>() + j0 * w1, h->ws_sel_g.as<float>() + j0 * w1,
+                                        b->stream, h->line_off.as<int64_t>(), h->line_len.as<int64_t>(), VLQ_LINE_MAX_CODES,
+                                        metaj, h->ws_sel_cnt.as<int32_t>() + j0);
+        }
         // the stored codes' share of the distance (line16c.hip), once per database state
         const bool use_consts = !rebuilt_rows && (h->row_mode == 0 || h->row_mode == 3) && with_meta && b->M == 16 &&
                                 b->ksub == 256 && w1 <= 1024 && h->ntotal > 0;
