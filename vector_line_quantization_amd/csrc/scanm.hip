@@ -5,8 +5,8 @@
 // (-2) * sim_table_2 (fvec_madd, IndexIVFPQ.cpp:641-644), dis = dis0 + tab[0][c0] + ... + tab[M-1][c_{M-1}] strictly left to
 // right (:788-794) -- so results cannot depend on which kernel served a query; what changes is how the work is laid out:
 //   * probe metadata gathered once per query into LDS, walking order without dead probes (ProbeMeta, scan16_common.cuh);
-//   * the table has M x 256 entries = M KB: the workgroup grows with it (4 waves up to 16 bytes, 8 for 32, 16 for 64), so a
-//     thread always owns 16 table entries (8 for M = 8): the same register footprint for every size;
+//   * the table has M x 256 entries = M KB: the workgroup grows with it (4 waves up to 16 bytes, 8 for 32 and 64): a thread
+//     owns 8 (M = 8), 16 or 32 (M = 64) table entries;
 //   * term2[key] and every lane's first code are requested one live probe ahead, the next chunk of a list before the current one
 //     is consumed; one workgroup barrier per probe with two table buffers (M <= 32), two with one (M = 64: 64 KB);
 //   * gathers in half blocks of 8 sub-quantizers: one SDWA op per code byte (byte extract and x4), sub-quantizer and buffer
@@ -74,10 +74,13 @@ __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ ba
 }
 
 template <int M> struct ScanMShape {
-    static constexpr int NW = M <= 16 ? 4 : M / 4;          // waves per workgroup
+    // waves per workgroup: 4 up to 16 bytes, 8 for 32 and for 64 (64-byte codes with 16 waves and 16 entries per thread measured
+    // 3.92 / 4.25 ms on the two bench data sets against 3.82 / 4.00 with 8 waves and 32 entries per thread -- 145 VGPRs, one
+    // workgroup per CU either way; forcing 128 VGPRs for two workgroups spills: 4.41 / 3.81)
+    static constexpr int NW = M <= 16 ? 4 : 8;
     static constexpr int NT = 64 * NW;
     static constexpr int E = M * 256;
-    static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8) or 4
+    static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8), 4, or 8 (M = 64)
 };
 
 template <int M, int KPL, int NBUF, bool IMI>
