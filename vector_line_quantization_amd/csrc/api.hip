@@ -596,7 +596,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                     // round of SHORT workgroups.  Measured (scan stage, G1 / headline data): 1100 queries 0.118 -> 0.103 / 0.139 ->
                     // 0.125 ms, 1250 queries 0.122 -> 0.118 / 0.146 -> 0.133; from the third round on (2500 queries) it no longer
                     // pays -- workgroups of an under-filled chip run faster as it is -- so only the second round is split
-                    const int64_t slots = 1024;
+                    const int64_t slots = (k <= 64 && !a.long_lists && h->imi_nbits == 0) ? 1280 : 1024;   // workgroups the chip holds (scan16.hip)
                     const int64_t rem = ni % slots;
                     int tp = rem > 0 ? (int)std::min<int64_t>(8, slots / rem) : 1;
                     tp = std::min(tp, nprobe / 4);

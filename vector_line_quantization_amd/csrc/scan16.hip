@@ -13,6 +13,8 @@
 //     mostly L2 hits instead of fabric reads.  Placement only affects speed.  (Walking a
 //     query's probes in the spatial order of their lists as well was measured and does not
 //     pay: the nearest lists must come first to tighten the admission threshold.)
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -604,7 +606,22 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     if (lutb < merge) lutb = merge;
     const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
     const size_t smem = lutb + tail;
-    if (a.k <= 64) launch_scan16_t<1, 4, 2, true>(a, (int)lutb, smem, s);
+    // k <= 64.  Lists of a few hundred codes (mean list < 1024 codes: every BASELINE shape but the long-list tools): ONE table
+    // buffer and the plain chunk loop -- 95 VGPRs and 19 KB of LDS = 5 workgroups per CU instead of 4.  Round 4, 10 000
+    // queries: G1 data 0.649 -> 0.606 ms (0.97 of the LDS gather rate), headline data 0.730 = 0.730 (row traffic bound); 2500
+    // queries 0.230 -> 0.215 / 0.192 -> 0.179 ms: 1280 slots hold a sharded batch's slice in fewer rounds.  Long lists keep two
+    // buffers and the pair loop (two chunks per trip, the adds of one under the gathers of the other).
+    // VLQ_SCAN16_VARIANT (A/B): 0 = two buffers + pair loop always, 2 = two buffers, plain loop, 3 = one buffer, pair loop.
+    static const int variant = [] { const char* e = getenv("VLQ_SCAN16_VARIANT"); return e ? atoi(e) : -1; }();
+    const bool plain = !a.part_keys && a.imi_nbits == 0;
+    if (a.k <= 64 && plain && (variant == 1 || (variant < 0 && !a.long_lists))) {
+        const size_t l1 = std::max((size_t)4096 * 4, merge);
+        launch_scan16_t<1, 4, 1, false>(a, (int)l1, l1 + tail, s);
+    } else if (a.k <= 64 && variant == 2 && plain) launch_scan16_t<1, 4, 2, false>(a, (int)lutb, smem, s);
+    else if (a.k <= 64 && variant == 3 && plain) {
+        const size_t l1 = std::max((size_t)4096 * 4, merge);
+        launch_scan16_t<1, 4, 1, true>(a, (int)l1, l1 + tail, s);
+    } else if (a.k <= 64) launch_scan16_t<1, 4, 2, true>(a, (int)lutb, smem, s);
     else if (a.k <= 128) {          // recall@100: half the merge network of the 256-key list
         if (a.long_lists) launch_scan16_t<2, 4, 2, true>(a, (int)lutb, smem, s);
         else launch_scan16_t<2, 4, 2, false>(a, (int)lutb, smem, s);
