@@ -94,6 +94,34 @@ def test_code_sizes_multi_index_table_type_2(M):
         assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
 
 
+@pytest.mark.parametrize("M,dsub", [(16, 8), (16, 6), (16, 4), (8, 16), (8, 12), (8, 8)])
+@pytest.mark.parametrize("nq,nprobe,k", [(1500, 16, 10), (40, 8, 1), (300, 33, 100), (64, 64, 300)])
+def test_table_mode_0_bit_exact(M, dsub, nq, nprobe, k):
+    """by_residual WITHOUT the precomputed table (use_precomputed_table = 0: GpuIndexIVFPQConfig's default; IndexIVFPQ.cpp:
+    636-638: residual distance tables per (query, list), dis0 = 0): the engineered kernel keeps the codebook in registers;
+    results equal the oracle's mode 0 bit for bit, including the seam with holes and the max_codes cut."""
+    rng, ox, g, gen = make(M, dsub, 96, 12000, 300 * M + dsub, long_frac=0.3)
+    g.set_search_options(by_residual=True, use_precomputed_table=0)
+    ox0 = OracleIndex(M * dsub, 96, M, 8, ox.coarse_centroids, ox.pq_centroids, codes=ox.codes, ids=ox.ids,
+                      list_offsets=ox.list_offsets, use_precomputed_table=0)
+    xq = gen(nq)
+    D, I = g.search(xq, nprobe, k)
+    Do, Io = ox0.search(xq, nprobe, k, canonical=True)
+    assert np.array_equal(bits(D), bits(Do))
+    assert np.array_equal(I, Io)
+    cd, keys = g.coarse_search(xq, nprobe)
+    keys = keys.copy()
+    keys[rng.random(keys.shape) < 0.2] = -1
+    D2, I2 = g.search_preassigned(xq, keys, cd, k, store_pairs=True)
+    Do2, Io2 = ox0.search_preassigned(xq, keys, cd, k, store_pairs=True, canonical=True)
+    assert np.array_equal(bits(D2), bits(Do2)) and np.array_equal(I2, Io2)
+    g.set_search_options(by_residual=True, use_precomputed_table=0, max_codes=400)
+    ox0.max_codes = 400
+    D3, I3 = g.search(xq, nprobe, k)
+    Do3, Io3 = ox0.search(xq, nprobe, k, canonical=True)
+    assert np.array_equal(bits(D3), bits(Do3)) and np.array_equal(I3, Io3)
+
+
 def test_engineered_equals_generic_kernel():
     """the same index through the generic kernel (a fresh process with VLQ_GENERIC_SCAN=1): identical rows"""
     import subprocess, sys, json

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def draw(seed):
     rng = np.random.default_rng(1000 + seed)
-    M = int(rng.choice([1, 2, 3, 4, 8, 16, 16, 16, 32]))
+    M = int(rng.choice([1, 2, 3, 4, 8, 8, 16, 16, 16, 32, 32, 64]))    # 8 / 32 / 64 x 8 bit in table mode 1: scanm.hip
     dsub = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12]))
     if M == 16 and rng.random() < 0.5:
         dsub = int(rng.choice([6, 8]))                       # the 16-byte fast path, both table sources
@@ -23,7 +23,7 @@ def draw(seed):
     d = M * dsub
     nlist = int(rng.choice([1, 2, 7, 33, 64, 130]))
     mode = int(rng.choice([0, 1, 1, 1, 2]))                   # 2 = not by_residual
-    nb = int(rng.choice([0, 5, 200, 3000]))
+    nb = int(rng.choice([0, 5, 200, 3000, 3000]))
     nq = int(rng.choice([1, 7, 19, 20, 33, 1100]))
     nprobe = int(rng.choice([1, 3, 16, 64, 200]))
     k = int(rng.choice([1, 5, 64, 65, 300]))

@@ -621,7 +621,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 }
             }
             tm.stop();
-        } else if (vlq::scanm_supports(a) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
+        } else if ((vlq::scanm_supports(a) || vlq::scanm0_supports(a)) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
             // 8 / 32 / 64-byte codes: the engineered organisation (scanm.hip); queries ordered like the 16-byte path
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);

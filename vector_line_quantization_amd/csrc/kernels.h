@@ -151,6 +151,7 @@ void launch_scan(const ScanArgs& a, hipStream_t s);
 // 8-, 32- and 64-byte codes (M x 8 bit), table mode 1 / table type 2, per-query table in a.qtab: scan16's organisation over the
 // code size (scanm.hip); same results as launch_scan
 bool scanm_supports(const ScanArgs& a);
+bool scanm0_supports(const ScanArgs& a);      // table mode 0, 8- / 16-byte codes (launch_scanm serves it too)
 void launch_scanm(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
+#include "sse_order.cuh"
 #include "wave_topk.cuh"
 
 namespace vlq {
@@ -83,9 +84,16 @@ template <int M> struct ScanMShape {
     static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8), 4, or 8 (M = 64)
 };
 
-template <int M, int KPL, int NBUF, bool IMI>
+// DSUB > 0: table mode 0 (by_residual WITHOUT the precomputed table -- GpuIndexIVFPQConfig::usePrecomputedTables = false, the
+// reference GPU class's default; IndexIVFPQ.cpp:636-637 on the CPU): the table of a (query, list) pair is
+// compute_distance_table(x - centroid) = |(x - c)_m - cent_mj|^2 in fvec_L2sqr's order (utils.cpp:481-506), dis0 = 0.  A thread
+// keeps the DSUB components of its 4 * NI centroids in registers for the whole query (d floats: 128 VGPRs at d = 128), the
+// residual of the NEXT probe is formed one probe ahead in LDS; the generic kernel re-read the 128 KB codebook from L2 per
+// probe (3.25 ms per 10 000 queries on the bench index against 0.73 with the precomputed table).
+template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0>
 __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, int lut_region) {
     constexpr int NW = ScanMShape<M>::NW, NT = ScanMShape<M>::NT, E = ScanMShape<M>::E, NI = ScanMShape<M>::NI;
+    static_assert(DSUB == 0 || (NBUF == 2 && !IMI), "table mode 0: two table buffers, flat coarse quantizer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [NBUF][E] at LDS byte 0
     u64* queue = reinterpret_cast<u64*>(smraw + lut_region);              // [NW][64]
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
     int32_t* misc = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(queue + NW * 64) + ProbeMeta::bytes(a.nprobe));
     uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
     uint32_t* wg_thr = reinterpret_cast<uint32_t*>(ord + ((a.nprobe + 1) & ~1));
+    float* sres = reinterpret_cast<float*>(wg_thr + 4);                          // [2][M * DSUB] residuals (table mode 0)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -117,7 +126,21 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
     const bool badkey = probe_meta_fill(a, q, pm, t, NT);
     // -2 * sim_table_2 of the query, entries 4*(i*NT+t) .. +3: sub-quantizer NW*i + wave, centroids 4*lane .. +3
     float4 m2t3[NI];
-    if (a.qtab) {                                   // materialised by launch_pq_tables
+    float cbk[DSUB > 0 ? NI * 4 * DSUB : 1];        // table mode 0: the thread's centroids, entry (i, c) = centroid 4*lane + c of m = NW*i + wave
+    float qmine = 0.f;                              // ... and component t of the query
+    if constexpr (DSUB > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const float4* src = reinterpret_cast<const float4*>(a.pq_cent + ((size_t)(NW * i + wave) * 256 + 4 * lane) * DSUB);
+#pragma unroll
+            for (int v = 0; v < DSUB; v++) {        // 4 * DSUB contiguous floats
+                const float4 f = src[v];
+                cbk[i * 4 * DSUB + 4 * v] = f.x; cbk[i * 4 * DSUB + 4 * v + 1] = f.y;
+                cbk[i * 4 * DSUB + 4 * v + 2] = f.z; cbk[i * 4 * DSUB + 4 * v + 3] = f.w;
+            }
+        }
+        if (t < M * DSUB) qmine = a.queries[q * (M * DSUB) + t];
+    } else if (a.qtab) {                            // materialised by launch_pq_tables
         const float4* qt = reinterpret_cast<const float4*>(a.qtab + q * E);
 #pragma unroll
         for (int i = 0; i < NI; i++) {
@@ -204,7 +227,9 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
             n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
                               __builtin_amdgcn_readfirstlane((uint32_t)o));
         }
-        if (IMI) {
+        if constexpr (DSUB > 0) {
+            // (table mode 0: no term2 row; the coarse centroid is requested by fetch_coarse, two probes ahead)
+        } else if (IMI) {
             // table type 2 (IndexIVFPQ.cpp:645-686): sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of the
             // coarse sub-index of its half
             const int64_t ki0 = key & ((int64_t(1) << a.imi_nbits) - 1), ki1 = key >> a.imi_nbits;
@@ -222,21 +247,56 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
     prefetch(i_begin);
+    // table mode 0: component t of the coarse centroid of the i-th walked probe, requested two probes ahead; the residual
+    // x - centroid (compute_residual, IndexIVFPQ.cpp:636) of the next probe is written to LDS while the current table is built
+    constexpr int DV = M * (DSUB > 0 ? DSUB : 1);
+    float cnext = 0.f;
+    int rb = 0;
+    auto fetch_coarse = [&](int i) __attribute__((always_inline)) {
+        if (DSUB == 0 || i >= nlive || t >= DV) return;
+        cnext = a.coarse[(size_t)pm.pkey[ord[i]] * DV + t];
+    };
+    if constexpr (DSUB > 0) {
+        fetch_coarse(i_begin);
+        if (t < DV) sres[t] = __fsub_rn(qmine, cnext);
+        fetch_coarse(i_begin + 1);
+        __syncthreads();
+    }
     int buf = 0;
     uint64_t nscan = 0;
     for (int i = i_begin; i < i_end; i++) {
         const uint32_t len = n_len, pos0 = n_pos0;
-        const float dis0 = n_dis0;
+        const float dis0 = DSUB > 0 ? 0.f : n_dis0;  // mode 0: dis0 = 0 (IndexIVFPQ.cpp:638)
         const int64_t off = n_off;
         float* L = lut + buf * E;
         if (NBUF == 1) __syncthreads();              // single table buffer: everyone is done scanning with it
         __builtin_amdgcn_s_setprio(2);               // table build + the next list's first loads first (scan16.hip)
+        if constexpr (DSUB > 0) {
+            if (t < DV && i + 1 < nlive) sres[(rb ^ 1) * DV + t] = __fsub_rn(qmine, cnext);
+            fetch_coarse(i + 2);
 #pragma unroll
-        for (int i2 = 0; i2 < NI; i2++) {
-            float4 sv;
-            sv.x = __fadd_rn(t2r[i2].x, m2t3[i2].x); sv.y = __fadd_rn(t2r[i2].y, m2t3[i2].y);
-            sv.z = __fadd_rn(t2r[i2].z, m2t3[i2].z); sv.w = __fadd_rn(t2r[i2].w, m2t3[i2].w);
-            reinterpret_cast<float4*>(L)[i2 * NT + t] = sv;
+            for (int i2 = 0; i2 < NI; i2++) {
+                const float* rs = sres + rb * DV + (NW * i2 + wave) * DSUB;      // wave-uniform: LDS broadcast reads
+                float r[DSUB];
+#pragma unroll
+                for (int c2 = 0; c2 < DSUB; c2++) r[c2] = rs[c2];
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float* cj = cbk + (i2 * 4 + c) * DSUB;
+                    v[c] = l2sqr_sse_order([&](int c2) { return r[c2]; }, [&](int c2) { return cj[c2]; }, DSUB);
+                }
+                reinterpret_cast<float4*>(L)[i2 * NT + t] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            rb ^= 1;
+        } else {
+#pragma unroll
+            for (int i2 = 0; i2 < NI; i2++) {
+                float4 sv;
+                sv.x = __fadd_rn(t2r[i2].x, m2t3[i2].x); sv.y = __fadd_rn(t2r[i2].y, m2t3[i2].y);
+                sv.z = __fadd_rn(t2r[i2].z, m2t3[i2].z); sv.w = __fadd_rn(t2r[i2].w, m2t3[i2].w);
+                reinterpret_cast<float4*>(L)[i2 * NT + t] = sv;
+            }
         }
         CodeWords<M> cc = c0;
         prefetch(i + 1);
@@ -295,16 +355,23 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
     if (badkey) *a.bad_key = 1;
 }
 
-template <int M, int KPL, int NBUF, bool IMI>
+template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0>
 static void launch_scanm_i(const ScanArgs& a, hipStream_t s) {
     constexpr int NW = ScanMShape<M>::NW, E = ScanMShape<M>::E;
     size_t lutb = (size_t)NBUF * E * 4;
     const size_t merge = (size_t)NW * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = (size_t)NW * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+    const size_t tail = (size_t)NW * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + (size_t)2 * M * DSUB * 4 + 16;
     const size_t smem = lutb + tail;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(scanm_kernel<M, KPL, NBUF, IMI>), smem);
-    hipLaunchKernelGGL((scanm_kernel<M, KPL, NBUF, IMI>), dim3((unsigned)(8 * a.xcd_chunk)), dim3(64 * NW), smem, s, a, (int)lutb);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scanm_kernel<M, KPL, NBUF, IMI, DSUB>), smem);
+    hipLaunchKernelGGL((scanm_kernel<M, KPL, NBUF, IMI, DSUB>), dim3((unsigned)(8 * a.xcd_chunk)), dim3(64 * NW), smem, s, a, (int)lutb);
+}
+// table mode 0 (DSUB = d / M components per sub-quantizer)
+template <int M, int DSUB>
+static void launch_scanm0_k(const ScanArgs& a, hipStream_t s) {
+    if (a.k <= 64) launch_scanm_i<M, 1, 2, false, DSUB>(a, s);
+    else if (a.k <= 256) launch_scanm_i<M, 4, 2, false, DSUB>(a, s);
+    else launch_scanm_i<M, 16, 2, false, DSUB>(a, s);
 }
 template <int M, int NBUF>
 static void launch_scanm_k(const ScanArgs& a, hipStream_t s) {
@@ -320,6 +387,14 @@ static void launch_scanm_k(const ScanArgs& a, hipStream_t s) {
 #undef VLQ_SM
 }
 
+// table mode 0 on the engineered kernel: 8- and 16-byte codes, flat coarse quantizer, d <= 128 (a thread holds d codebook floats)
+bool scanm0_supports(const ScanArgs& a) {
+    if (!(a.table_mode == 0 && a.ksub == 256 && a.imi_nbits == 0 && a.coarse && a.pq_cent && a.queries && a.nprobe <= 1024)) return false;
+    if (a.M == 16) return a.dsub == 4 || a.dsub == 6 || a.dsub == 8;
+    if (a.M == 8) return a.dsub == 8 || a.dsub == 12 || a.dsub == 16;
+    return false;
+}
+
 bool scanm_supports(const ScanArgs& a) {
     return (a.M == 8 || a.M == 32 || a.M == 64) && a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
            a.nprobe <= 1024 &&
@@ -331,6 +406,18 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
     ScanArgs a = a_in;
     if (a.nsplit < 1) a.nsplit = 1;
     a.xcd_chunk = (int)((a.nq * a.nsplit + 7) / 8);
+    if (a.table_mode == 0) {
+        if (a.M == 16) {
+            if (a.dsub == 8) launch_scanm0_k<16, 8>(a, s);
+            else if (a.dsub == 6) launch_scanm0_k<16, 6>(a, s);
+            else launch_scanm0_k<16, 4>(a, s);
+        } else {
+            if (a.dsub == 16) launch_scanm0_k<8, 16>(a, s);
+            else if (a.dsub == 12) launch_scanm0_k<8, 12>(a, s);
+            else launch_scanm0_k<8, 8>(a, s);
+        }
+        return;
+    }
     if (a.M == 8) launch_scanm_k<8, 2>(a, s);
     else if (a.M == 32) launch_scanm_k<32, 2>(a, s);    // two 32 KB buffers end at byte 65535: the last gather offset still fits
     else launch_scanm_k<64, 1>(a, s);
