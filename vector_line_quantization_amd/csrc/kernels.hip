@@ -11,6 +11,7 @@
 //                                                        -> scan_kernel
 //   compute_code                ProductQuantizer.cpp:311-336 -> encode_kernel
 #include "kernels.h"
+#include <type_traits>
 
 #include <map>
 #include <mutex>
@@ -329,48 +330,76 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
         // shadow.  No register more than the plain loop: two workgroups per CU as before.  Same products, same k
         // order per element, same epilogue arithmetic: bit-identical output.
         float pmrow[4] = {0.f, 0.f, 0.f, 0.f};     // TMIN == 8: running minimum of the tile's columns per row group
-        auto mfma_half = [&](int buf, int tj, f32x16& acc) __attribute__((always_inline)) {
+        // The epilogue of one 4-register group (4 consecutive rows x this lane's column) in four parts, so that it can
+        // be dealt out between the MFMAs of the next half: 0 / 1 distances of registers 0,1 / 2,3 ((x_norm + y_norm)
+        // - 2*ip, utils.cpp:884), 2 / 3 the two exchange steps of the 4x4 transpose inside a lane quad; part 3 ends
+        // with the 16-byte store (one row x 4 consecutive columns).
+        auto epi_part = [&](int m, int g, int tile, int tj, const f32x16& acc, float cnv, float (&v)[4]) __attribute__((always_inline)) {
+            if (m < 2) {
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
-            const float* bsrc = sm + buf * BUF + h * 64 * S + (tj * 32 + r) * S;
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bsrc + 4 * u);
-                const float4 av = areg[u];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc, 0, 0, 0);
-            }
-        };
-        auto epilogue_half = [&](int tile, int tj, const f32x16& acc) __attribute__((always_inline)) {
-            const float cnv = cn[tile * 64 + tj * 32 + r];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++)   // (x_norm + y_norm) - 2*ip, utils.cpp:884
+                for (int i = 2 * m; i < 2 * m + 2; i++)
                     v[i] = __fsub_rn(__fadd_rn(qnr[4 * g + i], cnv), __fmul_rn(2.f, acc[4 * g + i]));
-                {
-                    const bool odd = lane & 1;
-                    float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
-                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
-                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, false));
-                    if (odd) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
-                }
-                {
-                    const bool up = lane & 2;
-                    float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3];
-                    s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x4E, 0xf, 0xf, false));
-                    s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xf, 0xf, false));
-                    if (up) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
-                }
+            } else if (m == 2) {
+                const bool odd = lane & 1;
+                float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+                s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
+                s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, false));
+                if (odd) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+            } else {
+                const bool up = lane & 2;
+                float s0 = up ? v[0] : v[2], s1 = up ? v[1] : v[3];
+                s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x4E, 0xf, 0xf, false));
+                s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xf, 0xf, false));
+                if (up) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
                 const int64_t row = i0 + wave * 32 + 8 * g + 4 * h + (r & 3);
                 *reinterpret_cast<float4*>(out + row * nlist + tile * 64 + tj * 32 + (r & ~3)) = make_float4(v[0], v[1], v[2], v[3]);
                 if (TMIN == 8) {
                     const float m4 = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
                     pmrow[g] = tj == 0 ? m4 : fminf(pmrow[g], m4);
                 }
+            }
+        };
+        auto epilogue_half = [&](int tile, int tj, const f32x16& acc, float cnv) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) epi_part(m, g, tile, tj, acc, cnv, v);
+            }
+        };
+        // One half tile: the 4 NU MFMAs of (buf, tj) into acc and -- EPI -- the epilogue of the half before it
+        // (ptile, ptj, pacc), dealt out behind the MFMAs: a group of 4 dependent MFMAs occupies the pipe for 256 clocks,
+        // and the at most 12 VALU operations + one store issued after it finish inside the last one's 64.  The
+        // scheduler clustered all MFMAs in front of the whole epilogue whatever sched_group_barrier pattern asked for, so
+        // the order is pinned with full scheduling barriers here; the B operand of the next k group is read one group
+        // ahead.  Round-4 decomposition at C1 (10 000 x 4096 x 128, 474 workgroups on 512 slots, clocks 2.08 GHz under
+        // this load: the busiest SIMD's MFMAs alone are 87 us): loop without epilogue, staging and barrier 96 us;
+        // + epilogue arithmetic 14 (pinned or not), + matrix stores 15 (non-temporal: same), + staging 7.5,
+        // + barrier 1.6 = 127 us.
+        auto half_step = [&](auto epi, int buf, int tj, f32x16& acc, int ptile, int ptj, const f32x16& pacc, float pcn) __attribute__((always_inline)) {
+            constexpr bool EPI = decltype(epi)::value;
+            constexpr int P = NU / 4;                 // k groups per register group of the epilogue
+            const float* bsrc = sm + buf * BUF + h * 64 * S + (tj * 32 + r) * S;
+            float4 bcur = *reinterpret_cast<const float4*>(bsrc);
+            float v[4];
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                float4 bnext = bcur;
+                if (u + 1 < NU) bnext = *reinterpret_cast<const float4*>(bsrc + 4 * (u + 1));
+                const float4 av = areg[u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bcur.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bcur.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bcur.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bcur.w, acc, 0, 0, 0);
+                if (EPI) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+                        if (m * P / 4 == u % P) epi_part(m, u / P, ptile, ptj, pacc, pcn, v);
+                }
+                bcur = bnext;
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         // TMIN == 8, after both halves of a tile: the rows' tile minima (over lane bits 2..4), staged per wave and
@@ -397,24 +426,14 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         };
-        // issue order of a block: per MFMA two VALU operations of the epilogue; an LDS read of the next B operand
-        // every 4th MFMA, a matrix store every 16th (0x8 MFMA, 0x2 VALU, 0x100 DS read, 0x40 VMEM write)
-        auto schedule = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4 * NU; i++) {
-                if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                if (i % 16 == 15) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-            }
-        };
         f32x16 acc0, acc1;
-        mfma_half(0, 0, acc0);                       // first tile, first half: nothing to overlap with yet
+        const std::true_type with_epilogue{};
+        float cn0 = cn[tile0 * 64 + r], cn1 = 0.f;    // column norms of the halves in flight, requested one half ahead
+        half_step(std::false_type{}, 0, 0, acc0, 0, 0, acc0, 0.f);      // first tile, first half: nothing to overlap with yet
         for (int tile = tile0; tile < tend; tile++) {
             const int buf = (tile - tile0) & 1;
-            mfma_half(buf, 1, acc1);
-            epilogue_half(tile, 0, acc0);
-            schedule();
+            cn1 = cn[tile * 64 + 32 + r];
+            half_step(with_epilogue, buf, 1, acc1, tile, 0, acc0, cn0);
             // every wave has read its B operands of this tile: the next tile's registers go to the other buffer
             // (free since the barrier of the previous iteration), the tile after it is requested
             if (tile + 1 < tend) {
@@ -423,11 +442,10 @@ __global__ __launch_bounds__(256, 2) void coarse_dist_areg_kernel(
             }
             __syncthreads();
             if (tile + 1 < tend) {
-                mfma_half(buf ^ 1, 0, acc0);
-                epilogue_half(tile, 1, acc1);
-                schedule();
+                cn0 = cn[(tile + 1) * 64 + r];
+                half_step(with_epilogue, buf ^ 1, 0, acc0, tile, 1, acc1, cn1);
             } else {
-                epilogue_half(tile, 1, acc1);
+                epilogue_half(tile, 1, acc1, cn1);
             }
             if (TMIN == 8) tile_minima(tile);
         }
