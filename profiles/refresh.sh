@@ -1,12 +1,15 @@
 #!/bin/bash
-# Regenerates the inputs of the committed profiles on the GPU box (two gpurun calls, from the repo
-# root):  bash profiles/refresh.sh r02 a   (bench, kernel trace, PMC passes)
-#         bash profiles/refresh.sh r02 b   (sweeps, multi-index / VLQ / long-list / schedule runs)
-# -> gpurun_out/r02/...   then copy the summaries into profiles/ (python profiles/collect.py r02).
+# Regenerates the inputs of the committed profiles on the GPU box (one gpurun call per part, from the repo
+# root):  bash profiles/refresh.sh r04 a   (bench, kernel trace, PMC passes of the headline)
+#         bash profiles/refresh.sh r04 c   (PMC passes: first data set G1, list-owned schedule)
+#         bash profiles/refresh.sh r04 b   (sweeps, multi-index / VLQ / long-list / schedule runs)
+#         bash profiles/refresh.sh r04 e   (slices, host buffers, code sizes, table mode 0, coarse stage alone)
+#         bash profiles/refresh.sh r04 d   (VLQ at the driver's geometry, 998 M codes: kernel trace + PMC passes)
+# -> gpurun_out/r04/...   then copy the summaries into profiles/ (python profiles/collect.py r04).
 # Counter passes run without tracing domains.
 set -e
 R=${1:-r04}
-PART=${2:-ab}
+PART=${2:-acbed}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -19,6 +22,9 @@ $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- pyt
 echo "trace done" >&2
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc --no-second-dataset) > $OUT/pmc.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
+echo "pmc done" >&2
+fi
+if [[ $PART == *c* ]]; then
 # generator G1 as rounds 1-3 ran it (bench.py's first_dataset leg: sigma 0.03 isotropic, neighbouring queries share most probes)
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc2 --no-second-dataset --sigma 0.03 --rank 0 --spread 0) > $OUT/pmc2.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc2 > $OUT/pmc2_summary.txt
@@ -26,7 +32,16 @@ python $REPO/profiles/summarize_pmc.py $OUT/pmc2 > $OUT/pmc2_summary.txt
 # make it the default
 (cd $REPO && VLQ_SCAN_SCHEDULE=3 $T 600 bash profiles/pmc_passes.sh $OUT/pmc_owned --no-second-dataset) > $OUT/pmc_owned.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc_owned > $OUT/pmc_owned_summary.txt
-echo "pmc done" >&2
+echo "pmc2 / owned done" >&2
+fi
+if [[ $PART == *d* ]]; then
+export SYNTH=1 NLIST=65536 NEDGE=64 NB=1000000000
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vlq1b -- python $REPO/tools/time_vlq.py 2000 5 > $OUT/vlq1b_trace.log 2>&1
+FP16=1 $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vlq1b_fp16 -- python $REPO/tools/time_vlq.py 2000 5 > $OUT/vlq1b_fp16_trace.log 2>&1
+(cd $REPO && bash profiles/pmc_cmd.sh $OUT/pmc_vlq line tools/time_vlq.py 2000 3) > $OUT/pmc_vlq.log 2>&1
+(cd $REPO && FP16=1 bash profiles/pmc_cmd.sh $OUT/pmc_vlq_fp16 line tools/time_vlq.py 2000 3) > $OUT/pmc_vlq_fp16.log 2>&1
+unset SYNTH NLIST NEDGE NB
+echo "vlq pmc done" >&2
 fi
 if [[ $PART == *b* ]]; then
 $T 300 python $REPO/tools/sweep.py > $OUT/sweep.md 2> $OUT/sweep.err
@@ -47,7 +62,17 @@ echo "imi/vlq done" >&2
   NPROBE=64 K=10 $T 200 python $REPO/tools/long_lists.py 400000000 131072 10000 2>/dev/null | grep -v amdgpu
 } > $OUT/long_lists.txt
 KS=100,128,129,200,256,257,512,1000 $T 200 python $REPO/tools/large_k.py 2>/dev/null | grep total > $OUT/large_k.txt
+fi
+if [[ $PART == *e* ]]; then
 $T 200 python $REPO/tools/slice_stages.py 2>/dev/null | grep "^nq" > $OUT/slices.txt
 $T 200 python $REPO/tools/host_buffers.py 2>/dev/null | grep -v "amdgpu\|^\[bench\]" > $OUT/host_buffers.txt
+DATA=g1 $T 200 python $REPO/tools/slice_stages.py 2>/dev/null | grep "^nq" > $OUT/slices_g1.txt
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/code_sizes -- python $REPO/tools/time_code_sizes.py > $OUT/code_sizes.log 2>&1
+$T 200 python $REPO/tools/time_mode0.py > $OUT/mode0.log 2>&1
+$T 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/coarse -- python $REPO/tools/time_coarse.py > $OUT/coarse.log 2>&1
+NQ=2000 NLIST=65536 DIM=96 NPROBE=64 $T 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/coarse_vlq -- python $REPO/tools/time_coarse.py > $OUT/coarse_vlq.log 2>&1
 fi
+# only summaries travel back (gpurun merges at most 64 MiB)
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -size +512k -delete
 echo "all done" >&2
