@@ -449,6 +449,32 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         a.imi_nbits = h->imi_nbits;
         a.max_codes = h->max_codes;
         a.store_pairs = store_pairs;
+        // walking order of a query's probes (walk_order.cuh; speed only): the nearest probe first, the rest in list-id order
+        // for the batches whose workgroups compete for the fabric -- k <= 64 (longer selections pay more for the late
+        // admission bound than the rows save: k = 100 0.81 -> 0.84 ms), nprobe >= 16, 16- / 32-byte codes (8 KB rows and
+        // 64-byte codes at one workgroup per CU measured no gain), and only when the batch's neighbours share few lists
+        // (walk_stat_kernel below).  VLQ_WALK_FIRST = n forces n probes in front for every batch, -1 the reference's order.
+        static const int wf_env = [] { const char* e = getenv("VLQ_WALK_FIRST"); return e ? atoi(e) : -2; }();
+        const bool walk_rule = table_mode == 1 && h->imi_nbits == 0 && k <= 64 && nprobe >= 16 && (h->M == 16 || h->M == 32) &&
+                               h->ksub == 256 && ni >= 1024 && !h->fp16_tables;
+        a.walk_first = wf_env >= -1 ? wf_env : (walk_rule ? 1 : -1);
+        auto walk_decide = [&]() {        // after launch_query_order: flag behind the order's ni entries
+            if (wf_env >= -1 || a.walk_first < 0 || !a.qorder) return;
+            static const int share_max = [] { const char* e = getenv("VLQ_WALK_SHARE"); return e ? atoi(e) : 300; }();
+            int* part = h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3);       // 32 counts behind the order's ni entries
+            const int samples = vlq::launch_walk_stat(a.keys, a.qorder, ni, nprobe, part, h->stream);
+            // from 128 probes on the list-id order won on both data sets (G1 2.26 -> 1.97 ms, headline 3.02 -> 2.48)
+            a.walk_limit = (int)((int64_t)samples * (nprobe >= 128 ? 1000 : share_max) / 1000);
+            a.walk_flag = part;
+            if (getenv("VLQ_WALK_STAT_PRINT")) {
+                int v[32], tot = 0;
+                (void)hipStreamSynchronize(h->stream);
+                (void)hipMemcpy(v, part, sizeof(v), hipMemcpyDeviceToHost);
+                for (int x : v) tot += x;
+                fprintf(stderr, "[vlq] walk order: neighbours share %d of %d sampled probes -> %s\n", tot, samples,
+                        tot <= a.walk_limit ? "list-id order" : "coarse-distance order");
+            }
+        };
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
         if (h->fp16_tables && fast16 && h->imi_nbits == 0 && k <= 256) {
             // useFloat16LookupTables: half(term 2) once per trained state, half(term 3) per page, half table sums
@@ -462,7 +488,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 vlq::launch_to_half(h->ws_qtab.as<float>(), ni * (int64_t)E, -2.f, h->ws_qtabh.as<uint16_t>(), h->stream);
                 if (ni >= 1024) {
                     TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
-                    TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                    TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                     vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
                                             h->have_rank ? h->list_rank.as<int>() : nullptr);
                     a.qorder = h->ws_qorder.as<int>();
@@ -555,11 +581,12 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 StageTimer tq(h, 1);   // query ordering is booked with the table stage
                 // run queries that share their nearest centroid next to each other (L2 reuse)
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
-                TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,
                                         (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
                 a.qorder = h->ws_qorder.as<int>();
+                walk_decide();
                 tq.stop();
             }
             StageTimer tm(h, 2);       // exactly the scan kernel
@@ -626,10 +653,11 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
                 StageTimer tq(h, 1);
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
-                TRY(h->ws_qorder.reserve((size_t)ni * sizeof(int)));
+                TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
                                         (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
                 a.qorder = h->ws_qorder.as<int>();
+                walk_decide();
                 tq.stop();
             }
             StageTimer tm(h, 2);

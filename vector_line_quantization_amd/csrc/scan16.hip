@@ -20,6 +20,7 @@
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
+#include "walk_order.cuh"
 #include "wave_topk.cuh"
 
 namespace vlq {
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
+        if (!OWNED && nparts == 1) walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
         if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
     __syncthreads();
@@ -744,6 +746,43 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
     ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
     hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
                        hist + stride, qorder, list_rank, shift, nbins);
+}
+
+// ---------------------------------------------------------------------------
+// Which walking order (walk_order.cuh)?  Neighbours of the scan order that probe mostly the SAME lists (dense clusters: the
+// G1 generator setting, 750 shared probes of 1000) find each other's table rows in L2 anyway and lose the early admission
+// bound in list-id order (+2..5 % measured); neighbours that share few lists (150 of 1000 on the headline data) are the case
+// the list-id order is for (-12 %).  256 neighbour pairs of the scan order are sampled, one thread per (pair, probe of the
+// first query) among each one's nearest min(nprobe, 32); a workgroup leaves the count of its 8 pairs in part[blockIdx.x],
+// and the scan kernels add the 32 counts up themselves (walk_order_sort): no atomics, no zeroing, no host round trip.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restrict__ keys, const int* __restrict__ qorder, int nq,
+                                                        int nprobe, int pairs, int* __restrict__ part) {
+    __shared__ int red[4];
+    const int t = threadIdx.x;
+    const int np = min(nprobe, 32);
+    const int pair = blockIdx.x * 8 + (t >> 5), i = t & 31;
+    int shared = 0;
+    if (pair < pairs && i < np) {
+        const int s0 = (int)((int64_t)pair * (nq - 1) / pairs);
+        const int64_t x = keys[(int64_t)qorder[s0] * nprobe + i];
+        const int64_t* kb = keys + (int64_t)qorder[s0 + 1] * nprobe;
+        bool hit = false;
+#pragma unroll 8
+        for (int j = 0; j < np; j++) hit = hit || (kb[j] == x);
+        shared = (hit && x >= 0) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) shared += __shfl_down(shared, off);
+    if ((t & 63) == 0) red[t >> 6] = shared;
+    __syncthreads();
+    if (t == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// returns the number of (pair, probe) samples behind the 32 counts in part[]
+int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, hipStream_t s) {
+    const int pairs = (int)std::min<int64_t>(256, nq - 1);
+    hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part);
+    return pairs * std::min(nprobe, 32);
 }
 
 }  // namespace vlq

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
+#include "walk_order.cuh"
 #include "wave_topk.cuh"
 
 namespace vlq {
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void scan16h_kernel(ScanArgs a, int lut_region
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
+        walk_order_sort(a, pm, ord, nl, lane);
         if (lane == 0) { misc[0] = cut; misc[1] = nl; }
     }
     __syncthreads();

@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
+#include "walk_order.cuh"
 #include "wave_topk.cuh"
 
 namespace vlq {
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void scan16_bigk_kernel(ScanArgs a, int lut_re
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
+        walk_order_sort(a, pm, ord, nl, lane);
         if (lane == 0) { misc[0] = cut; misc[1] = nl; misc[2] = 0; misc[3] = (int32_t)__float_as_uint(3.402823466e+38f); }
     }
     __syncthreads();

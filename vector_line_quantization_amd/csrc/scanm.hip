@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "scan_common.cuh"
 #include "scan16_common.cuh"
+#include "walk_order.cuh"
 #include "sse_order.cuh"
 #include "wave_topk.cuh"
 
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
+        if (a.nsplit == 1) walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
         if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
     __syncthreads();
