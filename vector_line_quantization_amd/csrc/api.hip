@@ -455,16 +455,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         // 64-byte codes at one workgroup per CU measured no gain), and only when the batch's neighbours share few lists
         // (walk_stat_kernel below).  VLQ_WALK_FIRST = n forces n probes in front for every batch, -1 the reference's order.
         static const int wf_env = [] { const char* e = getenv("VLQ_WALK_FIRST"); return e ? atoi(e) : -2; }();
-        const bool walk_rule = table_mode == 1 && h->imi_nbits == 0 && k <= 64 && nprobe >= 16 && (h->M == 16 || h->M == 32) &&
-                               h->ksub == 256 && ni >= 1024 && !h->fp16_tables;
-        a.walk_first = wf_env >= -1 ? wf_env : (walk_rule ? 1 : -1);
+        const bool walk_base = table_mode == 1 && h->imi_nbits == 0 && (h->M == 16 || h->M == 32) && h->ksub == 256 && ni >= 1024 &&
+                               !h->fp16_tables;
+        // k <= 64 from 16 probes on; 64 < k <= 128 from 64 probes on with the 4 nearest in front (headline data, nprobe 64,
+        // k 100: 1.51 -> 1.38 ms; at nprobe 32 nothing to gain: 0.81 = 0.81) on indexes of short lists
+        const int walk_rule = !walk_base ? -1 : (k <= 64 && nprobe >= 16) ? 1
+                            : (k <= 128 && nprobe >= 64 && h->ntotal < (int64_t)h->nlist * 1024) ? 4 : -1;
+        a.walk_first = wf_env >= -1 ? wf_env : walk_rule;
         auto walk_decide = [&]() {        // after launch_query_order: flag behind the order's ni entries
             if (wf_env >= -1 || a.walk_first < 0 || !a.qorder) return;
             static const int share_max = [] { const char* e = getenv("VLQ_WALK_SHARE"); return e ? atoi(e) : 300; }();
             int* part = h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3);       // 32 counts behind the order's ni entries
             const int samples = vlq::launch_walk_stat(a.keys, a.qorder, ni, nprobe, part, h->stream);
             // from 128 probes on the list-id order won on both data sets (G1 2.26 -> 1.97 ms, headline 3.02 -> 2.48)
-            a.walk_limit = (int)((int64_t)samples * (nprobe >= 128 ? 1000 : share_max) / 1000);
+            a.walk_limit = (int)((int64_t)samples * ((nprobe >= 128 && k <= 64) ? 1000 : share_max) / 1000);
             a.walk_flag = part;
             if (getenv("VLQ_WALK_STAT_PRINT")) {
                 int v[32], tot = 0;
