@@ -462,11 +462,24 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         const int walk_rule = !walk_base ? -1 : (k <= 64 && nprobe >= 16) ? 1
                             : (k <= 128 && nprobe >= 64 && h->ntotal < (int64_t)h->nlist * 1024) ? 4 : -1;
         a.walk_first = wf_env >= -1 ? wf_env : walk_rule;
+        {
+            static const int wc = [] { const char* e = getenv("VLQ_WALK_CLOCK"); return e ? atoi(e) : 0; }();       // > 0 fixed period, < 0 no clock
+            static const int wscale = [] { const char* e = getenv("VLQ_WALK_SCALE"); return e ? atoi(e) : 1000; }();
+            a.walk_clock = wc > 0 ? wc : 0;
+            a.walk_scale = wscale;
+            if (wc == 0 && a.walk_first >= 0) {
+                // the workgroups' own walk times, per XCD; a new (nprobe, k, batch class) starts measuring afresh
+                if (!h->walk_state.p) { TRY(h->walk_state.reserve(8 * 16 * sizeof(int))); h->walk_key = -1; }
+                const int64_t wkey = ((int64_t)nprobe << 32) ^ ((int64_t)k << 16) ^ (int64_t)(ni >= 4096 ? 2 : 1);
+                if (wkey != h->walk_key) { (void)hipMemsetAsync(h->walk_state.p, 0, 8 * 16 * sizeof(int), h->stream); h->walk_key = wkey; }
+                a.walk_state = h->walk_state.as<int>();
+            }
+        }
         auto walk_decide = [&]() {        // after launch_query_order: flag behind the order's ni entries
             if (wf_env >= -1 || a.walk_first < 0 || !a.qorder) return;
             static const int share_max = [] { const char* e = getenv("VLQ_WALK_SHARE"); return e ? atoi(e) : 300; }();
             int* part = h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3);       // 32 counts behind the order's ni entries
-            const int samples = vlq::launch_walk_stat(a.keys, a.qorder, ni, nprobe, part, h->stream);
+            const int samples = vlq::launch_walk_stat(a.keys, a.qorder, ni, nprobe, part, a.walk_state, h->stream);
             // from 128 probes on the list-id order won on both data sets (G1 2.26 -> 1.97 ms, headline 3.02 -> 2.48)
             a.walk_limit = (int)((int64_t)samples * ((nprobe >= 128 && k <= 64) ? 1000 : share_max) / 1000);
             a.walk_flag = part;
@@ -475,8 +488,10 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 (void)hipStreamSynchronize(h->stream);
                 (void)hipMemcpy(v, part, sizeof(v), hipMemcpyDeviceToHost);
                 for (int x : v) tot += x;
-                fprintf(stderr, "[vlq] walk order: neighbours share %d of %d sampled probes -> %s\n", tot, samples,
-                        tot <= a.walk_limit ? "list-id order" : "coarse-distance order");
+                int ws[8 * 16] = {0};
+                if (a.walk_state) (void)hipMemcpy(ws, a.walk_state, sizeof(ws), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[vlq] walk order: neighbours share %d of %d sampled probes -> %s; walk ticks per XCD %d %d %d %d %d %d %d %d\n", tot, samples,
+                        tot <= a.walk_limit ? "list-id order" : "coarse-distance order", ws[0], ws[16], ws[32], ws[48], ws[64], ws[80], ws[96], ws[112]);
             }
         };
         const bool fast16 = table_mode == 1 && h->M == 16 && h->ksub == 256;
@@ -788,7 +803,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_own_recs, &h->ws_own_seg, &h->ws_own_items, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->stats, &h->imi_cent,
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi,
                       // the float16 screen of the coarse stage: built for every index at set_coarse_centroids
                       &h->screen.half, &h->screen.mu, &h->screen.norm_c, &h->imi_screen[0].half, &h->imi_screen[0].mu,

@@ -138,7 +138,8 @@ struct vlq_ivfpq_s {
     // workspace
     DevBuf ws_Dp, ws_Ip;          // partial top-k rows of the split scan (small batches)
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
-        ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin;
+        ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin, walk_state;
+    int64_t walk_key = -1;       // (nprobe, k, batch class) the walk times in walk_state were measured for
     // float16 look-up tables of the plain IVFPQ scan (vlq_ivfpq_set_float16_tables): half(term2), per-page half(term3)
     bool fp16_tables = false, term2h_valid = false;
     DevBuf term2h, ws_qtabh;

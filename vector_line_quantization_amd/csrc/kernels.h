@@ -129,6 +129,9 @@ struct ScanArgs {
     int* tail_rows = nullptr;    // [8 * tail_r], preset to -1
     int xcd_chunk = 0;           // set by the launcher
     const int* walk_flag = nullptr;  // optional: walk_stat_kernel's 32 counts of probes shared by neighbours of the scan order ...
+    int walk_clock = 0;              // A/B: fixed period of the walk clock in 10 ns ticks (VLQ_WALK_CLOCK)
+    int* walk_state = nullptr;       // per XCD (16 ints apart): running mean of a workgroup's walk time, kept across launches
+    int walk_scale = 1000;           // period = measured walk time x this / 1000
     int walk_limit = 0;              // ... list-id order only while their sum is <= this
     int walk_first = -1;         // walk_order.cuh: < 0 = probes in coarse-distance order, else this many nearest first, the rest by list id
     int grid_per_xcd = 0;        // set by the launcher: workgroups per XCD (xcd_chunk unless the tail is split)
@@ -193,7 +196,7 @@ inline size_t query_order_bins_padded(int nlist) {
     return (nbins + 63) & ~(size_t)63;
 }
 // samples neighbour pairs of the scan order and decides the walking order of the probes (scan16.hip, walk_order.cuh)
-int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, hipStream_t s);
+int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s);
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank = nullptr);

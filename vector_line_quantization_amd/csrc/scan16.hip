@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         }
     };
     const int i_begin = (int)((int64_t)part * nlive / nparts), i_end = (int)((int64_t)(part + 1) * nlive / nparts);
+    const unsigned long long t_walk = wall_clock64();
     prefetch(i_begin);
     int buf = 0;
     uint64_t nscan = 0;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         nscan += len;
         if (NBUF == 2) buf ^= 1;
     }
+    if (!OWNED && nparts == 1 && a.walk_first >= 0 && t == 0) walk_state_update(a, t_walk, i_end - i_begin);
 
     if (OWNED) {
         // raw keys out: scan positions are global to the query, so owned_merge_kernel can order the
@@ -757,8 +759,10 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
 // and the scan kernels add the 32 counts up themselves (walk_order_sort): no atomics, no zeroing, no host round trip.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restrict__ keys, const int* __restrict__ qorder, int nq,
-                                                        int nprobe, int pairs, int* __restrict__ part) {
+                                                        int nprobe, int pairs, int* __restrict__ part, int* __restrict__ walk_state) {
     __shared__ int red[4];
+    // this launch's clock period per XCD = the running mean of the walk times measured so far (walk_order.cuh)
+    if (walk_state && blockIdx.x == 0 && threadIdx.x < 8) walk_state[threadIdx.x * 16 + 1] = walk_state[threadIdx.x * 16];
     const int t = threadIdx.x;
     const int np = min(nprobe, 32);
     const int pair = blockIdx.x * 8 + (t >> 5), i = t & 31;
@@ -779,9 +783,9 @@ __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restric
 }
 
 // returns the number of (pair, probe) samples behind the 32 counts in part[]
-int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, hipStream_t s) {
+int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s) {
     const int pairs = (int)std::min<int64_t>(256, nq - 1);
-    hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part);
+    hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part, walk_state);
     return pairs * std::min(nprobe, 32);
 }
 

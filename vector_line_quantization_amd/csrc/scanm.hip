@@ -248,6 +248,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
         c0 = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t, n_len - 1));
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
+    const unsigned long long t_walk = wall_clock64();
     prefetch(i_begin);
     // table mode 0: component t of the coarse centroid of the i-th walked probe, requested two probes ahead; the residual
     // x - centroid (compute_residual, IndexIVFPQ.cpp:636) of the next probe is written to LDS while the current table is built
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
         nscan += len;
         if (NBUF == 2) buf ^= 1;
     }
+    if (a.nsplit == 1 && a.walk_first >= 0 && t == 0) walk_state_update(a, t_walk, i_end - i_begin);
     merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                             [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
