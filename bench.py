@@ -306,7 +306,7 @@ def self_launch(args):
 def sources_sha():
     import hashlib
     hh = hashlib.sha256()
-    for f in ("scan16.hip", "scan16_common.cuh", "wave_topk.cuh", "scan_common.cuh"):
+    for f in ("scan16.hip", "scan16_common.cuh", "wave_topk.cuh", "scan_common.cuh", "walk_order.cuh"):
         with open(os.path.join(ROOT, "vector_line_quantization_amd", "csrc", f), "rb") as fh:
             hh.update(fh.read())
     return hh.hexdigest()
