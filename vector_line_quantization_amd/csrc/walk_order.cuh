@@ -3,13 +3,23 @@
 // The reference scans a query's lists in coarse-distance order (IndexIVFPQ.cpp:983-1060); what a result depends on is each
 // code's distance and its scan POSITION (the tie order of the heap replay), and positions are fixed per probe before the walk
 // starts (ProbeMeta::cum).  The order in which a workgroup actually visits its probes is therefore free -- the list-owned
-// schedule already uses that.  Here: the nearest `first` probes stay in front (they tighten the admission bound early), the
-// rest is visited in ascending list id.  Queries that run next to each other on an XCD probe overlapping sets of lists; when
-// every workgroup walks its set in the same global order, two workgroups that started at about the same time ask for a shared
-// 16 KB table row at about the same time, and the second request finds it in the XCD's L2 instead of crossing the fabric.
-// Headline data (10 000 queries, nprobe 32): scan 0.725 -> 0.632 ms; all probes by id (first = 0) 0.641; 2 / 4 / 8 in front
-// 0.636 / 0.647 / 0.668.  (A walk that STARTS where the XCD's other workgroups currently are -- all workgroups on the same
-// rows at once -- was measured too: 1.69 ms.)
+// schedule already uses that.  Two steps, both measured on the headline data (10 000 queries, nprobe 32, k 10; the kernel
+// was bound by the 16 KB table rows crossing the fabric into the XCDs: 5.38 GB per launch, L2 hit 36 %):
+//  1. the nearest `first` probes stay in front (they tighten the admission bound early), the rest is visited in ascending
+//     list id.  Queries that run next to each other on an XCD probe overlapping sets of lists; when every workgroup walks its
+//     set in the same global order, two workgroups that started at about the same time ask for a shared row at about the
+//     same time and the second request finds it in the XCD's L2.  Scan 0.725 -> 0.638 ms, 4.37 GB, L2 hit 48 %
+//     (all probes by id 0.641; 2 / 4 / 8 in front 0.636 / 0.647 / 0.668);
+//  2. the walk is cyclic and starts at the id a global clock (s_memrealtime, 100 MHz, one counter for the chip) points at,
+//     period = the time a walk takes, measured by the workgroups themselves (walk_state): whenever a workgroup starts, it
+//     joins the others of its XCD near the same id.  0.638 -> 0.597 ms, 3.43 GB, L2 hit 59 %; nprobe 64 1.24 -> 1.08 ms,
+//     nprobe 128 2.52 -> 2.04 ms (coarse-distance order: 1.47 / 3.02).  Period = 0.6 / 0.8 x the measured walk time: 0.619 /
+//     0.600; 1.2 / 1.5 x: 0.603 / 0.606.  Every workgroup of a launch must use the SAME period (the clock counts from boot:
+//     a period that differs by 0.2 % is a random phase -- a running mean read live measured 0.75 ms).
+// What did not work: publishing the position through device-scope atomics (one store per probe to a line per XCD: 1.69 ms);
+// non-temporal code loads to keep the rows in L2 longer (0.72: neighbours share the codes too); centring a workgroup's
+// walk on the clock by its share of the codes (no change); 8-byte codes / float16 rows (8 KB rows: 0.371 -> 0.387) and
+// 64-byte codes (one workgroup per CU: 3.84 -> 3.89) -- the rule in api.hip keeps those in coarse-distance order.
 #pragma once
 #include "scan16_common.cuh"
 
