@@ -475,18 +475,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 a.walk_state = h->walk_state.as<int>();
             }
         }
-        auto walk_decide = [&]() {        // after launch_query_order: flag behind the order's ni entries
-            if (wf_env >= -1 || a.walk_first < 0 || !a.qorder) return;
+        // the statistic is computed with the scan order (launch_query_order); behind the order's ni entries: its 32 counts
+        const bool walk_auto = wf_env < -1 && a.walk_first >= 0;
+        auto walk_part = [&]() -> int* { return walk_auto ? h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3) : nullptr; };
+        auto walk_decide = [&]() {        // after launch_query_order
+            if (!walk_auto || !a.qorder) return;
             static const int share_max = [] { const char* e = getenv("VLQ_WALK_SHARE"); return e ? atoi(e) : 300; }();
-            int* part = h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3);       // 32 counts behind the order's ni entries
-            const int samples = vlq::launch_walk_stat(a.keys, a.qorder, ni, nprobe, part, a.walk_state, h->stream);
+            const int samples = vlq::walk_stat_samples(ni, nprobe);
             // from 128 probes on the list-id order won on both data sets (G1 2.26 -> 1.97 ms, headline 3.02 -> 2.48)
             a.walk_limit = (int)((int64_t)samples * ((nprobe >= 128 && k <= 64) ? 1000 : share_max) / 1000);
-            a.walk_flag = part;
+            a.walk_flag = walk_part();
             if (getenv("VLQ_WALK_STAT_PRINT")) {
                 int v[32], tot = 0;
                 (void)hipStreamSynchronize(h->stream);
-                (void)hipMemcpy(v, part, sizeof(v), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(v, a.walk_flag, sizeof(v), hipMemcpyDeviceToHost);
                 for (int x : v) tot += x;
                 int ws[8 * 16] = {0};
                 if (a.walk_state) (void)hipMemcpy(ws, a.walk_state, sizeof(ws), hipMemcpyDeviceToHost);
@@ -603,7 +605,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -674,7 +676,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();

@@ -199,7 +199,9 @@ inline size_t query_order_bins_padded(int nlist) {
 int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s);
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank = nullptr);
+                        int* qorder, hipStream_t s, const int* list_rank = nullptr, int* walk_part = nullptr, int* walk_state = nullptr);
+// walk_part (optional): the walking-order statistic (32 counts, see launch_walk_stat) is computed along with the order
+int walk_stat_samples(int64_t nq, int nprobe);
 
 // merge of per-shard results [nparts][nq][k] into the global top-k (list-sharded multi-GPU mode)
 void launch_merge_topk(const float* Dp, const int64_t* Ip, int64_t nq, int k, int nparts, float* D,

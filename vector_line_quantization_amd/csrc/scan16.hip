@@ -687,6 +687,20 @@ __global__ __launch_bounds__(256) void qorder_place_kernel(const int64_t* __rest
 // batch sharded over several GPUs): bin counts, their exclusive prefix and the placement -- one launch
 // instead of a memset and two kernels: 15 -> 8 us at 1250 queries.  (At 10 000 queries one workgroup is too
 // serial: 33 us against 17.)
+// one (pair of neighbours in the scan order, probe of the first) sample of walk_stat_kernel (below)
+__device__ __forceinline__ int walk_stat_sample(const int64_t* __restrict__ keys, const int* qorder, int nq, int nprobe, int pairs,
+                                                int pair, int i) {
+    const int np = min(nprobe, 32);
+    if (pair >= pairs || i >= np) return 0;
+    const int s0 = (int)((int64_t)pair * (nq - 1) / pairs);
+    const int64_t x = keys[(int64_t)qorder[s0] * nprobe + i];
+    const int64_t* kb = keys + (int64_t)qorder[s0 + 1] * nprobe;
+    bool hit = false;
+#pragma unroll 8
+    for (int j = 0; j < np; j++) hit = hit || (kb[j] == x);
+    return (hit && x >= 0) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __restrict__ keys, int nq, int nprobe, int nlist,
                                                              int* __restrict__ qorder, const int* __restrict__ list_rank,
                                                              int shift, int nbins) {
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __re
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank) {
+                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state) {
     if (nq <= 0) return;
     // at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
     // by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
@@ -737,6 +751,8 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
         ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_single_kernel), smem1);
         hipLaunchKernelGGL(qorder_single_kernel, dim3(1), dim3(1024), smem1, s, keys, (int)nq, nprobe, nlist, qorder, list_rank,
                            shift, nbins);
+        // (the statistic inside this one-workgroup kernel was measured: 8192 samples on one CU cost 36 us against 5)
+        if (walk_part && nq >= 2) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s);
         return;
     }
     const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
@@ -748,6 +764,7 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
     ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
     hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
                        hist + stride, qorder, list_rank, shift, nbins);
+    if (walk_part) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -764,18 +781,7 @@ __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restric
     // this launch's clock period per XCD = the running mean of the walk times measured so far (walk_order.cuh)
     if (walk_state && blockIdx.x == 0 && threadIdx.x < 8) walk_state[threadIdx.x * 16 + 1] = walk_state[threadIdx.x * 16];
     const int t = threadIdx.x;
-    const int np = min(nprobe, 32);
-    const int pair = blockIdx.x * 8 + (t >> 5), i = t & 31;
-    int shared = 0;
-    if (pair < pairs && i < np) {
-        const int s0 = (int)((int64_t)pair * (nq - 1) / pairs);
-        const int64_t x = keys[(int64_t)qorder[s0] * nprobe + i];
-        const int64_t* kb = keys + (int64_t)qorder[s0 + 1] * nprobe;
-        bool hit = false;
-#pragma unroll 8
-        for (int j = 0; j < np; j++) hit = hit || (kb[j] == x);
-        shared = (hit && x >= 0) ? 1 : 0;
-    }
+    int shared = walk_stat_sample(keys, qorder, nq, nprobe, pairs, blockIdx.x * 8 + (t >> 5), t & 31);
     for (int off = 32; off > 0; off >>= 1) shared += __shfl_down(shared, off);
     if ((t & 63) == 0) red[t >> 6] = shared;
     __syncthreads();
@@ -783,6 +789,8 @@ __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restric
 }
 
 // returns the number of (pair, probe) samples behind the 32 counts in part[]
+int walk_stat_samples(int64_t nq, int nprobe) { return (int)std::min<int64_t>(256, nq - 1) * std::min(nprobe, 32); }
+
 int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s) {
     const int pairs = (int)std::min<int64_t>(256, nq - 1);
     hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part, walk_state);
