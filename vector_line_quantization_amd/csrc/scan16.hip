@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
     float4 m2t3[NI];
     load_query_table16<NI>(a, q, t, lane, wave, m2t3);
     __syncthreads();
+    int walk_mean = -1;        // thread 0: walk_order.cuh
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
         __builtin_amdgcn_wave_barrier();
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
-        if (!OWNED && nparts == 1) walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
+        if (!OWNED && nparts == 1) walk_mean = walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
         if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
     __syncthreads();
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((KPL =
         nscan += len;
         if (NBUF == 2) buf ^= 1;
     }
-    if (!OWNED && nparts == 1 && a.walk_first >= 0 && t == 0) walk_state_update(a, t_walk, i_end - i_begin);
+    if (t == 0) walk_state_finish(a, t_walk, i_end - i_begin, walk_mean);
 
     if (OWNED) {
         // raw keys out: scan positions are global to the query, so owned_merge_kernel can order the

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
         for (int i = 0; i < NI; i++) m2t3[i] = reinterpret_cast<const float4*>(lut)[i * NT + t];   // the thread's own stores
     }
     __syncthreads();
+    int walk_mean = -1;        // thread 0: walk_order.cuh
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
         __builtin_amdgcn_wave_barrier();
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
-        if (a.nsplit == 1) walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
+        if (a.nsplit == 1) walk_mean = walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
         if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
     __syncthreads();
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, in
         nscan += len;
         if (NBUF == 2) buf ^= 1;
     }
-    if (a.nsplit == 1 && a.walk_first >= 0 && t == 0) walk_state_update(a, t_walk, i_end - i_begin);
+    if (t == 0) walk_state_finish(a, t_walk, i_end - i_begin, walk_mean);
     merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,
                             [&](int p, int64_t& lkey, int64_t& loff) { lkey = kq[p]; loff = pm.poff[p]; });
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);

@@ -26,14 +26,16 @@
 namespace vlq {
 
 // wave 0 of the workgroup, after ord[0 .. nl) holds the live probes in coarse-distance order
-__device__ __forceinline__ void walk_order_sort(const ScanArgs& a, const ProbeMeta& pm, uint16_t* ord, int nl, int lane) {
+// returns -1 when the coarse-distance order stays, else the running mean of the walk time as read now (0 = none yet): the
+// value walk_state_finish folds this workgroup's own time into
+__device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMeta& pm, uint16_t* ord, int nl, int lane) {
     const int first = a.walk_first;
-    if (first < 0 || nl - first < 2 || nl - first > 256) return;
+    if (first < 0 || nl - first < 2 || nl - first > 256) return -1;
     if (a.walk_flag) {      // walk_stat_kernel: do this batch's neighbours share most of their lists anyway?
         int v = lane < 32 ? a.walk_flag[lane] : 0;
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (__builtin_amdgcn_readfirstlane(v) > a.walk_limit) return;
+        if (__builtin_amdgcn_readfirstlane(v) > a.walk_limit) return -1;
     }
     __builtin_amdgcn_wave_barrier();
     const int n = nl - first;
@@ -64,6 +66,8 @@ __device__ __forceinline__ void walk_order_sort(const ScanArgs& a, const ProbeMe
     // within L2's memory.
     int rot = 0;
     long long period = a.walk_clock;
+    int mean_now = 0;
+    if (a.walk_state) mean_now = a.walk_state[(blockIdx.x & 7) * 16];
     if (period == 0 && a.walk_state) {
         // plain accesses: a stale value is as good as a fresh one, and device-scope atomics leave the XCD (measured: +17 %)
         const int dur = a.walk_state[(blockIdx.x & 7) * 16 + 1];      // the same value for every workgroup of this launch
@@ -78,17 +82,17 @@ __device__ __forceinline__ void walk_order_sort(const ScanArgs& a, const ProbeMe
     for (int c = 0; c < 4; c++)
         if (lane + 64 * c < n) { int pos = rank[c] - rot; if (pos < 0) pos += n; ord[first + pos] = (uint16_t)p[c]; }
     __builtin_amdgcn_wave_barrier();
+    return max(mean_now, 0);
 }
 
-// thread 0 of a workgroup after its walk: running mean (1/8) of the walk time in clock ticks, per XCD
-__device__ __forceinline__ void walk_state_update(const ScanArgs& a, unsigned long long t_begin, int nprobes_walked) {
-    if (!a.walk_state || nprobes_walked < 8) return;
-    int* st = a.walk_state + (blockIdx.x & 7) * 16;
+// thread 0 of a workgroup after its walk: running mean (1/8) of the walk time in clock ticks, per XCD.  `mean` was read at the
+// start of the workgroup (a load here would sit between the last probe and the release of the workgroup's slot: measured
+// +2 % on the scan); the store is not waited for.
+__device__ __forceinline__ void walk_state_finish(const ScanArgs& a, unsigned long long t_begin, int nprobes_walked, int mean) {
+    if (!a.walk_state || mean < 0 || nprobes_walked < 8) return;
     const long long d = (long long)(wall_clock64() - t_begin);
     if (d < 100 || d > 100000000) return;
-    const int old = *st;
-    const int nw = old > 0 ? old + (int)((d - old) / 8) : (int)d;
-    *st = nw;
+    a.walk_state[(blockIdx.x & 7) * 16] = mean > 0 ? mean + (int)((d - mean) / 8) : (int)d;
 }
 
 }  // namespace vlq
