@@ -1,4 +1,4 @@
-"""GPU: the walking order of a query's probes (csrc/walk_order.cuh) is a schedule, not arithmetic: whatever order a workgroup
+"""GPU: the walking order of a query's probes (csrc/walk_order.cuh) and the workgroup shape of the 16-byte scan are schedules, not arithmetic: whatever order a workgroup
 visits its lists in -- the reference's coarse-distance order (IndexIVFPQ.cpp:983-1060), the nearest n first and the rest by list
 id, or the library's own per-batch decision -- distances, labels and the tie order must equal the oracle's, bit for bit.  The
 library reads its A/B switches once per process, so every setting runs in a fresh process that checks itself."""
@@ -19,7 +19,7 @@ from util import bits
 out = {}
 for M, dsub in ((16, 4), (32, 2), (8, 4)):
     rng, ox, g, gen = t.make(M, dsub, 160, 30000, 31 * M + dsub, long_frac=0.2)
-    for nq, nprobe, k in ((1500, 32, 10), (1100, 16, 64), (1300, 150, 10), (1200, 40, 100), (300, 32, 10)):
+    for nq, nprobe, k in ((1500, 32, 10), (1100, 16, 64), (1300, 150, 10), (1200, 40, 100), (300, 32, 10), (3100, 24, 20)):
         xq = gen(nq)
         xq[:10] = ox.coarse_centroids[:10]
         Do, Io = ox.search(xq, nprobe, k, canonical=True)
@@ -50,7 +50,9 @@ def runs():
     for name, extra in (("library", {}), ("reference_order", {"VLQ_WALK_FIRST": "-1"}), ("all_by_id", {"VLQ_WALK_FIRST": "0"}),
                         ("one_first", {"VLQ_WALK_FIRST": "1"}), ("five_first", {"VLQ_WALK_FIRST": "5"}),
                         ("always_decide_id", {"VLQ_WALK_SHARE": "1000"}), ("fixed_clock", {"VLQ_WALK_SHARE": "1000", "VLQ_WALK_CLOCK": "777"}),
-                        ("no_clock", {"VLQ_WALK_SHARE": "1000", "VLQ_WALK_CLOCK": "-1"})):
+                        ("no_clock", {"VLQ_WALK_SHARE": "1000", "VLQ_WALK_CLOCK": "-1"}),
+                        # the two workgroup shapes of the 16-byte kernel (two waves from 3000 queries on by default)
+                        ("two_waves", {"VLQ_SCAN16_VARIANT": "4", "VLQ_WALK_SHARE": "1000"}), ("four_waves", {"VLQ_SCAN16_VARIANT": "1"})):
         env = dict(os.environ)
         env.update(extra)
         p = subprocess.run([sys.executable, "-c", CODE], cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -60,7 +62,7 @@ def runs():
 
 
 def test_every_walking_order_equals_the_oracle(runs):
-    assert len(runs) == 8       # each process asserted its rows against the oracle
+    assert len(runs) == 10       # each process asserted its rows against the oracle
 
 
 def test_walking_orders_agree_with_each_other(runs):

@@ -619,7 +619,16 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     // VLQ_SCAN16_VARIANT (A/B): 0 = two buffers + pair loop always, 2 = two buffers, plain loop, 3 = one buffer, pair loop.
     static const int variant = [] { const char* e = getenv("VLQ_SCAN16_VARIANT"); return e ? atoi(e) : -1; }();
     const bool plain = !a.part_keys && a.imi_nbits == 0;
-    if (a.k <= 64 && plain && (variant == 1 || (variant < 0 && !a.long_lists))) {
+    // ... and from 3000 queries on TWO waves per workgroup (a thread owns 32 table entries: 127 VGPRs, 8 workgroups per CU = 2048
+    // slots): a list of 330 codes is 3 trips of 128 lanes instead of 2 trips of 256 -- 25 % fewer lane slots, and a two-wave
+    // barrier.  10 000 queries: headline data 0.604 -> 0.548 ms, nprobe 16 / 64 / 128 0.356 / 1.08 / 2.04 -> 0.327 / 0.99 / 1.92,
+    // k = 50 0.649 -> 0.563, G1 0.626 -> 0.595; below 3000 queries the 2048 slots of slower workgroups lose to 1280 (2500
+    // queries 0.183 -> 0.202, 1250 queries on G1 0.101 -> 0.116).  VLQ_SCAN16_VARIANT = 4 / 1 force two / four waves.
+    if (a.k <= 64 && plain && !a.tail_r && a.nsplit == 1 && (variant == 4 || (variant < 0 && !a.long_lists && a.nq >= 3000))) {
+        const size_t l1 = std::max((size_t)4096 * 4, (size_t)2 * a.k * 8);
+        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+        launch_scan16_t<1, 2, 1, false>(a, (int)l1, l1 + tail2, s);
+    } else if (a.k <= 64 && plain && (variant == 1 || (variant < 0 && !a.long_lists))) {
         const size_t l1 = std::max((size_t)4096 * 4, merge);
         launch_scan16_t<1, 4, 1, false>(a, (int)l1, l1 + tail, s);
     } else if (a.k <= 64 && variant == 2 && plain) launch_scan16_t<1, 4, 2, false>(a, (int)lutb, smem, s);
