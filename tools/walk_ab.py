@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda", 0)
-base = argparse.Namespace(nq=10000, nb=1000000, nt=100000, d=128, nlist=4096, M=16, nprobe=32, k=10, sigma=0.005,
+base = argparse.Namespace(nq=10000, nb=1000000, nt=100000, d=128, nlist=4096, M=int(os.environ.get("M", 16)), nprobe=32, k=10, sigma=0.005,
                           gmm_centres=2000, rank=12, spread=0.4)
 for name, kw in (("headline", {}), ("G1", dict(sigma=0.03, rank=0, spread=0.0))):
     a = copy.copy(base)

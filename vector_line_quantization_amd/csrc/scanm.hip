@@ -5,10 +5,10 @@
 // (-2) * sim_table_2 (fvec_madd, IndexIVFPQ.cpp:641-644), dis = dis0 + tab[0][c0] + ... + tab[M-1][c_{M-1}] strictly left to
 // right (:788-794) -- so results cannot depend on which kernel served a query; what changes is how the work is laid out:
 //   * probe metadata gathered once per query into LDS, walking order without dead probes (ProbeMeta, scan16_common.cuh);
-//   * the table has M x 256 entries = M KB: the workgroup grows with it (4 waves up to 16 bytes, 8 for 32 and 64): a thread
-//     owns 8 (M = 8), 16 or 32 (M = 64) table entries;
+//   * the table has M x 256 entries = M KB: 4 waves per workgroup up to 32 bytes, 8 for 64 (ScanMShape): a thread owns 8
+//     (M = 8), 16 or 32 (M = 32, 64) table entries;
 //   * term2[key] and every lane's first code are requested one live probe ahead, the next chunk of a list before the current one
-//     is consumed; one workgroup barrier per probe with two table buffers (M <= 32), two with one (M = 64: 64 KB);
+//     is consumed; one workgroup barrier per probe with two table buffers (M <= 16), two with one (M = 32, 64);
 //   * gathers in half blocks of 8 sub-quantizers: one SDWA op per code byte (byte extract and x4), sub-quantizer and buffer
 //     offsets in the ds_read offset field, two half blocks in flight while the previous one is added;
 //   * XCD-aware placement of the sorted query order, shared admission threshold of the workgroup's waves.
@@ -76,13 +76,18 @@ __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ ba
 }
 
 template <int M> struct ScanMShape {
-    // waves per workgroup: 4 up to 16 bytes, 8 for 32 and for 64 (64-byte codes with 16 waves and 16 entries per thread measured
-    // 3.92 / 4.25 ms on the two bench data sets against 3.82 / 4.00 with 8 waves and 32 entries per thread -- 145 VGPRs, one
-    // workgroup per CU either way; forcing 128 VGPRs for two workgroups spills: 4.41 / 3.81)
-    static constexpr int NW = M <= 16 ? 4 : 8;
+    // waves per workgroup: 4 up to 32 bytes, 8 for 64.
+    // 32-byte codes ran 8 waves x 16 entries per thread with two 32 KB buffers (2 workgroups per CU) until late round 4; 4 waves
+    // x 32 entries with ONE buffer (128 VGPRs forced, 4 workgroups per CU) halves the lane slots a ~330-code list leaves empty
+    // (256-wide trips instead of 512) -- 10 000 queries: headline data 1.36 -> 1.24 ms, G1 1.37 -> 1.16 (the LDS gather rate of
+    // tools/micro/lds_gather.hip), k = 100 1.75 -> 1.62 / 1.21, k = 200 2.5 -> 1.66; a 1250-query slice loses 8 % (0.222 -> 0.242).
+    // 8-byte codes with 2 waves measured slower (0.371 -> 0.388).  64-byte codes with 16 waves and 16 entries per thread
+    // measured 3.92 / 4.25 ms on the two bench data sets against 3.82 / 4.00 with 8 waves and 32 entries per thread -- 145
+    // VGPRs, one workgroup per CU either way; forcing 128 VGPRs for two workgroups spills: 4.41 / 3.81.
+    static constexpr int NW = M <= 32 ? 4 : 8;
     static constexpr int NT = 64 * NW;
     static constexpr int E = M * 256;
-    static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8), 4, or 8 (M = 64)
+    static constexpr int NI = E / 4 / NT;                    // float4 of the table per thread: 2 (M = 8), 4, or 8 (M = 32, 64)
 };
 
 // DSUB > 0: table mode 0 (by_residual WITHOUT the precomputed table -- GpuIndexIVFPQConfig::usePrecomputedTables = false, the
@@ -92,7 +97,7 @@ template <int M> struct ScanMShape {
 // residual of the NEXT probe is formed one probe ahead in LDS; the generic kernel re-read the 128 KB codebook from L2 per
 // probe (3.25 ms per 10 000 queries on the bench index against 0.73 with the precomputed table).
 template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0>
-__global__ __launch_bounds__(ScanMShape<M>::NT) void scanm_kernel(ScanArgs a, int lut_region) {
+__global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_eu((M == 32 && DSUB == 0 && KPL == 1) ? 4 : 1))) void scanm_kernel(ScanArgs a, int lut_region) {
     constexpr int NW = ScanMShape<M>::NW, NT = ScanMShape<M>::NT, E = ScanMShape<M>::E, NI = ScanMShape<M>::NI;
     static_assert(DSUB == 0 || (NBUF == 2 && !IMI), "table mode 0: two table buffers, flat coarse quantizer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
@@ -424,7 +429,7 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
         return;
     }
     if (a.M == 8) launch_scanm_k<8, 2>(a, s);
-    else if (a.M == 32) launch_scanm_k<32, 2>(a, s);    // two 32 KB buffers end at byte 65535: the last gather offset still fits
+    else if (a.M == 32) launch_scanm_k<32, 1>(a, s);     // one 32 KB buffer, 4 waves (ScanMShape)
     else launch_scanm_k<64, 1>(a, s);
 }
 
