@@ -24,7 +24,7 @@ def draw(seed):
     nlist = int(rng.choice([1, 2, 7, 33, 64, 130]))
     mode = int(rng.choice([0, 1, 1, 1, 2]))                   # 2 = not by_residual
     nb = int(rng.choice([0, 5, 200, 3000, 3000]))
-    nq = int(rng.choice([1, 7, 19, 20, 33, 1100]))
+    nq = int(rng.choice([1, 7, 19, 20, 33, 1100, 3100]))      # 3100: the two-wave workgroups of scan16 (from 3000 queries on)
     nprobe = int(rng.choice([1, 3, 16, 64, 200]))
     k = int(rng.choice([1, 5, 64, 65, 300]))
     max_codes = int(rng.choice([0, 0, 0, 50, 400]))
