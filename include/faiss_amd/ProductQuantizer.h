@@ -41,6 +41,31 @@ struct ProductQuantizer {
       memcpy(get_centroids(m, 0), clus.centroids.data(), ksub * dsub * sizeof(float));
     }
   }
+  /// fvec_L2sqr in the reference's operation order (utils.cpp:481-506): four lane sums s[l] += (x-y)^2 with multiply and
+  /// add kept apart, zero-padded tail, then (s0+s1)+(s2+s3) -- the order the device encoder uses (sse_order.cuh), so that
+  /// encode() and encode_multiple() pick the same centroid on near-ties.  No FMA contraction whatever the host flags.
+#if defined(__clang__)
+  static float l2sqr_lane_order(const float* x, const float* y, size_t d) {
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+  __attribute__((optimize("fp-contract=off"))) static float l2sqr_lane_order(const float* x, const float* y, size_t d) {
+#else
+  static float l2sqr_lane_order(const float* x, const float* y, size_t d) {
+#endif
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    size_t i = 0;
+    for (; i + 4 <= d; i += 4)
+      for (size_t l = 0; l < 4; l++) { const float t = x[i + l] - y[i + l]; const float p = t * t; s[l] = s[l] + p; }
+    if (i < d) {
+      for (size_t l = 0; l < 4; l++) {
+        const float t = (i + l < d) ? x[i + l] - y[i + l] : 0.f;
+        const float p = t * t;
+        s[l] = s[l] + p;
+      }
+    }
+    const float a = s[0] + s[1], b = s[2] + s[3];
+    return a + b;
+  }
   /// nearest centroid per sub-quantizer, first minimum wins (ProductQuantizer.cpp:311-336: fvec_L2sqr_ny + strict <).
   /// Host-side, one vector at a time; bulk encoding goes through the device (IndexIVFPQ::encode_multiple).
   void compute_code(const float* x, uint8_t* code) const {
@@ -50,9 +75,7 @@ struct ProductQuantizer {
       float best = 3.402823466e+38f;
       size_t bi = 0;
       for (size_t j = 0; j < ksub; j++) {
-        const float* c = get_centroids(m, j);
-        float dis = 0;
-        for (size_t i = 0; i < dsub; i++) { const float t = xs[i] - c[i]; dis += t * t; }
+        const float dis = l2sqr_lane_order(xs, get_centroids(m, j), dsub);
         if (dis < best) { best = dis; bi = j; }
       }
       code[m] = (uint8_t)bi;

@@ -779,13 +779,13 @@ int vlq_ivfpq_create(vlq_ivfpq_t* out, int device, int d, int nlist, int M, int 
     if (const char* e = getenv("VLQ_COARSE_SCREEN")) h->coarse_screen = atoi(e);   // 0: f32 MFMA matrix path everywhere (A/B)
     if (const char* e = getenv("VLQ_COARSE_FILTER")) h->coarse_filter = atoi(e);   // 1: filtered coarse stage (A/B; slower)
     h->h_lists_stale = true;    // host copies of the list starts / lengths are filled on first use
-    int rc = h->stats.reserve(64);     // [0] ncode, [1] flag word; [2..7] phase clocks of instrumented builds (-DVLQ_PHASE_TIMING)
+    int rc = h->stats.reserve(512);    // [0] ncode, [1] flag word; [2..7] phase clocks of instrumented builds (-DVLQ_PHASE_TIMING), [8..47] (-DVLQ_SCAN16_PHASES)
     if (rc == VLQ_OK) rc = h->list_off.reserve(((size_t)nlist + 1) * 8);
     if (rc == VLQ_OK) rc = h->list_len.reserve((size_t)nlist * 8);
     if (rc == VLQ_OK) rc = h->codes.reserve(16);
     if (rc == VLQ_OK) rc = h->ids.reserve(16);
     if (rc != VLQ_OK) { vlq_ivfpq_destroy(h); return rc; }
-    (void)hipMemsetAsync(h->stats.p, 0, 64, h->stream);
+    (void)hipMemsetAsync(h->stats.p, 0, 512, h->stream);
     (void)hipMemsetAsync(h->list_off.p, 0, ((size_t)nlist + 1) * 8, h->stream);
     (void)hipMemsetAsync(h->list_len.p, 0, (size_t)nlist * 8, h->stream);
     (void)hipStreamSynchronize(h->stream);
@@ -1259,17 +1259,39 @@ int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out) {
 int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     TRY(set_dev(h));
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 64, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long st[64] = {0};
+    HIP_TRY(hipMemcpyAsync(st, h->stats.p, 512, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (nq) *nq = h->stat_nq;
     if (ncode) *ncode = st[0];
+    if (st[8 + 14] && getenv("VLQ_SCAN16_PHASES")) {    // only a scan16 built with -DVLQ_SCAN16_PHASES writes these (scan16.hip)
+        static const char* names[14] = {"set-up: second barrier, first prefetch", "barrier before the table build", "wait for the prefetched row (vmcnt)",
+                                        "table build + next prefetch issued", "barrier after the build", "admission bound refresh",
+                                        "gather trips + selection", "merge + rows out", "set-up: placement", "set-up: probe keys, list offsets",
+                                        "set-up: per-query table", "set-up: first barrier", "set-up: prefix sums, live probes (wave 0)",
+                                        "set-up: walking order (wave 0)"};
+        static const int order[14] = {8, 9, 10, 11, 12, 13, 0, 1, 2, 3, 4, 5, 6, 7};
+        for (int w = 0; w < 2; w++) {
+            const unsigned long long* o = st + 8 + 20 * w;
+            if (!o[14]) continue;
+            const double wg = (double)o[14], probes = (double)(o[15] & 0xffffffffull), trips = (double)(o[15] >> 32);
+            fprintf(stderr, "[scan16 phases] wave %d: %llu workgroups sampled, %.1f probes and %.1f trips each, %.0f cycles = %.2f us per workgroup "
+                            "(clock %.2f GHz)\n", w, o[14], probes / wg, trips / wg, o[16] / wg, o[17] * 0.01 / wg, o[16] / (o[17] * 10.0));
+            fprintf(stderr, "[scan16 phases]   (of the gather trips: the 16 gathers + adds of a trip %.0f cycles per trip, %.0f per workgroup)\n",
+                    o[18] / trips, o[18] / wg);
+            for (int j = 0; j < 14; j++) {
+                const int i = order[j];
+                fprintf(stderr, "[scan16 phases]   %-44s %9.0f cycles per workgroup  %7.1f per probe  %5.1f %%\n", names[i], o[i] / wg,
+                        o[i] / probes, 100.0 * o[i] / o[16]);
+            }
+        }
+    }
     if (st[5] && getenv("VLQ_PHASE_TIMING"))     // only kernels built with -DVLQ_PHASE_TIMING write these
         fprintf(stderr, "[phase timing] per workgroup: prologue %.2f us, loop %.2f us, tail %.2f us (%llu workgroups)\n",
                 st[2] * 0.01 / st[5], st[3] * 0.01 / st[5], st[4] * 0.01 / st[5], st[5]);
     const int bad = (int)(st[1] & 0xffffffffu);
     if (reset) {
-        HIP_TRY(hipMemsetAsync(h->stats.p, 0, 64, h->stream));
+        HIP_TRY(hipMemsetAsync(h->stats.p, 0, 512, h->stream));
         h->stat_nq = 0;
     } else if (bad) {       // the flag is consumed by the error it raises; the counters stay
         HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(h->stats.p) + 8, 0, 8, h->stream));

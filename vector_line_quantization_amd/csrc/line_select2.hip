@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NT) void line_select2_kernel(
     uint32_t* kimg = reinterpret_cast<uint32_t*>(smraw);                 // [KP][NT] ordered key images (0xffffffff: invalid); thread t owns column t
     u64* win = reinterpret_cast<u64*>(kimg + NT * KP);                   // [NS] winners, then sorted
     uint32_t* hist = reinterpret_cast<uint32_t*>(win + NS);              // [256] radix bins; later [nprobe] anchor bins
-    uint32_t* misc = hist + (nprobe > 256 ? nprobe : 256);               // [16]: scan scratch, digit, counts
+    uint32_t* misc = hist + (nprobe > 256 ? ((nprobe + 1) & ~1) : 256);  // [16]: scan scratch, digit, counts (even bin count: ebits below is 8-byte aligned)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t q = blockIdx.x;
     const float* row = dist + q * nlist;
@@ -334,7 +334,7 @@ template <int KP, int NS>
 static void launch_ls2(const float* dist, int64_t nq, int nlist, const int64_t* keys, int nprobe, const int32_t* edge_info,
                        const float* edge_dist, int nedge, int w1, int32_t* sel_line, float* sel_b2, float* sel_g, hipStream_t s,
                        const int64_t* line_off, const int64_t* line_len, int max_line_codes, LineMeta* sel_meta, int32_t* sel_cnt) {
-    const size_t smem = (size_t)NT * KP * 4 + (size_t)NS * 8 + (size_t)(nprobe > 256 ? nprobe : 256) * 4 + 16 * 4 + (size_t)nprobe * 8;
+    const size_t smem = (size_t)NT * KP * 4 + (size_t)NS * 8 + (size_t)(nprobe > 256 ? ((nprobe + 1) & ~1) : 256) * 4 + 16 * 4 + (size_t)nprobe * 8;
     ensure_dynamic_lds(reinterpret_cast<const void*>(line_select2_kernel<KP, NS>), smem);
     hipLaunchKernelGGL((line_select2_kernel<KP, NS>), dim3((unsigned)nq), dim3(NT), smem, s, dist, nq, nlist, keys, nprobe, edge_info,
                        edge_dist, nedge, w1, sel_line, sel_b2, sel_g, line_off, line_len, max_line_codes, sel_meta, sel_cnt);

@@ -25,6 +25,43 @@
 
 namespace vlq {
 
+// Phase clocks of the query-major kernel (diagnostic builds only: make FLAGS_scan16=-DVLQ_SCAN16_PHASES; tools/scan16_phases.py).
+// s_memtime = shader cycles; sums per phase of a sample of workgroups go to stats[8 + 20 * wave ..] (vlq_ivfpq_stats prints
+// them); no result is computed from a stamp.  The build also waits for the prefetched row explicitly before the table build,
+// so that waiting for memory and storing the table are two phases.
+// Ablation builds (tools/build_variant.sh ablN "-DVLQ_SCAN16_ABL=N" scan16): kernel TIME with one part of the probe loop removed --
+// results are wrong under every one of them.  Bits: 1 no selection, 2 no gathers, 4 no table stores, 8 no row loads, 16 no code reloads
+#ifndef VLQ_SCAN16_ABL
+#define VLQ_SCAN16_ABL 0
+#endif
+#ifdef VLQ_SCAN16_PHASES
+#define VLQ_PH_DECL                                              \
+    uint64_t ph_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    uint64_t ph_last_ = __builtin_amdgcn_s_memtime();            \
+    const uint64_t ph_t0_ = ph_last_, ph_rt0_ = wall_clock64();  \
+    uint32_t ph_trips_ = 0;                                      \
+    uint64_t ph_g_ = 0, ph_g0_ = 0
+#define VLQ_PH(i)                                                \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        const uint64_t n_ = __builtin_amdgcn_s_memtime();        \
+        asm volatile("" ::: "memory");                           \
+        ph_[i] += n_ - ph_last_;                                 \
+        ph_last_ = n_;                                           \
+    } while (0)
+#define VLQ_PH_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define VLQ_PH_TRIP() ph_trips_++
+#define VLQ_PH_G0() do { asm volatile("" ::: "memory"); ph_g0_ = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
+#define VLQ_PH_G1() do { asm volatile("" ::: "memory"); ph_g_ += __builtin_amdgcn_s_memtime() - ph_g0_; asm volatile("" ::: "memory"); } while (0)
+#else
+#define VLQ_PH_G0() do {} while (0)
+#define VLQ_PH_G1() do {} while (0)
+#define VLQ_PH_DECL
+#define VLQ_PH(i) do {} while (0)
+#define VLQ_PH_VMWAIT() do {} while (0)
+#define VLQ_PH_TRIP() do {} while (0)
+#endif
+
 // IMI: table type 2 (multi-index: two term2 rows per list) -- a compile-time switch, the row
 // addressing sits in the per-probe prefetch
 // OWNED: the list-owned schedule (kernels.h): the workgroup is one (query, list partition) item
@@ -43,8 +80,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                                                ProbeMeta::bytes(a.nprobe));    // cut, nlive
     uint16_t* ord = reinterpret_cast<uint16_t*>(misc + 2);                      // [nprobe] visited probes, in walking order
     uint32_t* wg_thr = reinterpret_cast<uint32_t*>(ord + ((a.nprobe + 1) & ~1));  // min of the waves' k-th distances
+    // nprobe <= 64 (round 5): the probes' metadata once more, in WALKING order -- list offsets and scan positions here, lengths /
+    // list ids / coarse distances permuted in place in pm -- so that the probe loop reads probe i's five values at index i
+    // in one LDS round trip instead of ord[i] -> p -> pm.*[p] in two (the round trips wait behind the CU's gathers)
+    const bool recs = a.nprobe <= 64;
+    int64_t* w_off = reinterpret_cast<int64_t*>((reinterpret_cast<uintptr_t>(wg_thr + 1) + 7) & ~(uintptr_t)7);   // [nprobe]
+    uint32_t* w_pos = reinterpret_cast<uint32_t*>(w_off + a.nprobe);                                              // [nprobe]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    VLQ_PH_DECL;
     // adc16_fixed() addresses the LUT buffers at LDS offsets 0 / 16384
     if (__builtin_amdgcn_groupstaticsize() != 0) { *a.bad_key = 2; return; }
     uint32_t two = 2;
@@ -99,10 +143,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
     const int64_t* kq = a.keys + q * a.nprobe;
 
     // ---- per-query set-up -------------------------------------------------------
+    VLQ_PH(8);
     const bool badkey = probe_meta_fill(a, q, pm, t, NT);
+    VLQ_PH(9);
     float4 m2t3[NI];
     load_query_table16<NI>(a, q, t, lane, wave, m2t3);
+    WalkPre wpre;
+    if (!OWNED && wave == 0) wpre = walk_prefetch(a, lane);       // in flight across the barrier and the prefix sums
+    VLQ_PH(10);
     __syncthreads();
+    VLQ_PH(11);
     int walk_mean = -1;        // thread 0: walk_order.cuh
     if (wave == 0) {
         const int cut = probe_meta_scan(a, pm, lane);
@@ -116,9 +166,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
-        if (!OWNED && nparts == 1) walk_mean = walk_order_sort(a, pm, ord, nl, lane);    // parts are merged in part order = scan order
+        VLQ_PH(12);
+        if (!OWNED && nparts == 1) walk_mean = walk_order_sort(a, pm, ord, nl, lane, wpre);    // parts are merged in part order = scan order
+        if (recs) {
+            const int p = lane < nl ? ord[lane] : 0;
+            const int32_t k_ = pm.pkey[p];
+            const uint32_t l_ = pm.plen[p], c_ = pm.cum[p];
+            const float d_ = pm.pd0[p];
+            const int64_t o_ = pm.poff[p];
+            __builtin_amdgcn_wave_barrier();           // (LDS operations of one wave complete in order: every read above precedes the writes)
+            if (lane < nl) { pm.pkey[lane] = k_; pm.plen[lane] = l_; pm.pd0[lane] = d_; w_off[lane] = o_; w_pos[lane] = c_; }
+        }
         if (lane == 0) { misc[0] = cut; misc[1] = nl; *wg_thr = f32_to_ordered(3.402823466e+38f); }
     }
+    VLQ_PH(13);
     __syncthreads();
     const int nlive = misc[1];
 
@@ -127,16 +188,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
 
     // ---- probe loop, software-pipelined one live probe ahead ----------------------
     float4 t2r[NI];
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = make_uint4(0, 0, 0, 0);
+    // The codes of a list are requested one PROBE ahead, chunk by chunk (round 5): cr[c] holds chunk c (this thread's code of
+    // trip c) of the list about to be scanned and is reloaded with the next list's chunk c in the trip that consumed it.  Until
+    // round 4 only the first chunk came a probe ahead and every later one a single trip ahead: a trip's 16 gathers and adds
+    // take ~580 cycles, a code load under the scan's fabric traffic ~1500 -- every trip but the first of a list waited ~900
+    // cycles for its codes (profiles/r05_scan16_phases.txt).  Same register count: three chunks in flight either way.
+    // (the long selections, KPL >= 4, keep one chunk a probe ahead and the rest a trip ahead: their merge networks leave no
+    // registers for more)
+    constexpr bool AHEAD = !PIPE && KPL <= 2;
+    constexpr int NPRE = !AHEAD ? 2 : (NW == 2 ? 3 : 2);
+    uint4 cr[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     // the prefetched probe's metadata is carried into the iteration that scans it (wave-uniform
     // values): the loop top has no LDS round trips of its own
     uint32_t n_len = 0, n_pos0 = 0;
     float n_dis0 = 0.f;
     int64_t n_off = 0;
-    auto prefetch = [&](int i) {     // i-th probe of the walking order
+    // Two steps (round 5): the probe's metadata (wave-uniform: LDS -> scalar registers) while the table is being built, the
+    // global loads -- the 16 KB row, the list's first codes -- only AFTER the first trip has requested the current list's
+    // second chunk.  vmcnt retires in order: with the row (fabric latency, 8 loads) issued ahead of that chunk, the second
+    // trip of every probe waited for the NEXT probe's row (profiles/r05_scan16_phases.txt: 1410 cycles per trip on the
+    // headline's 330-code lists against 920 on G1, whose rows are L2 hits).
+    int64_t n_key = 0;
+    auto prefetch_meta = [&](int i) {     // i-th probe of the walking order
         if (i >= nlive) return;      // (a part may look one probe past its range: harmless loads)
+        if (recs) {
+            n_key = (int64_t)__builtin_amdgcn_readfirstlane(pm.pkey[i]);
+            n_len = __builtin_amdgcn_readfirstlane(pm.plen[i]);
+            n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[i])));
+            n_pos0 = __builtin_amdgcn_readfirstlane(w_pos[i]);
+            const int64_t o = w_off[i];
+            n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
+                              __builtin_amdgcn_readfirstlane((uint32_t)o));
+            return;
+        }
         const int p = ord[i];
-        const int64_t key = pm.pkey[p];
+        n_key = (int64_t)__builtin_amdgcn_readfirstlane(pm.pkey[p]);
         n_len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
         n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
         n_pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
@@ -145,6 +231,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
             n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
                               __builtin_amdgcn_readfirstlane((uint32_t)o));
         }
+    };
+    auto load_rows = [&]() {
+        const int64_t key = n_key;
         if (IMI) {
             // table type 2: sub-quantizer m = NW*i + wave takes its 1 KB slice from the row of
             // the coarse sub-index of its half (IndexIVFPQ.cpp:645-686)
@@ -159,18 +248,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
         }
-        {   // this thread's first two codes of the list, clamped (branch-free loads)
-            const uint4* cpn = reinterpret_cast<const uint4*>(a.codes) + n_off;
-            const uint32_t last = n_len - 1;
-            c0 = cpn[min((uint32_t)t, last)];
-            c1 = cpn[min((uint32_t)t + NT, last)];
-        }
     };
+    // this thread's code of trip c of the prefetched list, clamped (branch-free loads)
+    auto load_chunk = [&](auto cc_) {
+        constexpr int C = decltype(cc_)::value;
+        cr[C] = (reinterpret_cast<const uint4*>(a.codes) + n_off)[min((uint32_t)t + C * NT, n_len - 1)];
+    };
+    auto prefetch_loads = [&](int i) {
+        if (i >= nlive) return;
+        load_rows();
+        load_chunk(std::integral_constant<int, 0>{});
+        load_chunk(std::integral_constant<int, 1>{});
+        if (NPRE == 3) load_chunk(std::integral_constant<int, 2>{});
+    };
+    auto prefetch = [&](int i) { prefetch_meta(i); prefetch_loads(i); };
     const int i_begin = (int)((int64_t)part * nlive / nparts), i_end = (int)((int64_t)(part + 1) * nlive / nparts);
     const unsigned long long t_walk = wall_clock64();
     prefetch(i_begin);
+    // (the first table build needs the row at once, so nothing is lost by waiting for the set-up's loads here -- and with
+    // nothing pending on the way into the loop the compiler counts the loads younger than a row exactly: entering with the
+    // prologue's loads in another order than the loop's it waited for vmcnt(0) in the middle of EVERY table build, i.e. for
+    // the chunk requested in the trip just finished)
+    if (AHEAD) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
     int buf = 0;
     uint64_t nscan = 0;
+    VLQ_PH(0);
     for (int i = i_begin; i < i_end; i++) {
         const uint32_t len = n_len;
         const float dis0 = n_dis0;
@@ -178,21 +280,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
         const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + n_off;
         float* L = lut + buf * E;
         if (NBUF == 1) __syncthreads();   // single LUT buffer: everyone is done scanning with it
+        VLQ_PH(1);
+        VLQ_PH_VMWAIT();
+        VLQ_PH(2);
         // the table build and the next list's first loads at raised wave priority: the workgroup's
         // other waves wait at the barrier below for the slowest builder, whose stores and global
         // loads otherwise queue behind the gathers of the CU's other workgroups (scan 0.665 ->
         // 0.655 ms at the headline shape; levels 1..3 measure the same)
         __builtin_amdgcn_s_setprio(2);
-        build_lut16<NI>(L, t, t2r, m2t3);
-        uint4 cc = c0, cd = c1;
-        prefetch(i + 1);
+        if (VLQ_SCAN16_ABL & 4) {
+#pragma unroll
+            for (int i2 = 0; i2 < NI; i2++) asm volatile("" :: "v"(t2r[i2].x), "v"(t2r[i2].y), "v"(t2r[i2].z), "v"(t2r[i2].w));
+        } else build_lut16<NI>(L, t, t2r, m2t3);
+        uint4 cc = cr[0], cd = cr[1];
+        // a list longer than NPRE chunks: its next four chunks requested now (the row registers are free once the table is
+        // stored), in flight across the barrier
+        const uint32_t w64x = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64 + NPRE * NT;
+        const bool hasx = AHEAD && w64x < len;
+        constexpr int NEX = KPL == 1 ? 4 : 2;      // (two for the 128-key selections: their registers)
+        uint4 ex[NEX];
+        if (hasx) {
+#pragma unroll
+            for (int e = 0; e < NEX; e++) ex[e] = cp[min(w64x + e * NT + lane, len - 1)];
+        }
+        if (!AHEAD) prefetch(i + 1);
+        else prefetch_meta(i + 1);
         __builtin_amdgcn_s_setprio(0);
+        VLQ_PH(3);
         __syncthreads();
+        VLQ_PH(4);
         if (sel.dirty) {     // wave-uniform: publish this wave's k-th distance, then take the workgroup's minimum
             if (lane == 0) atomicMin(wg_thr, f32_to_ordered(sel.thr_own));
             sel.dirty = false;
         }
         sel.refresh_with(*wg_thr);
+        VLQ_PH(5);
         // one copy of the list loop per LUT buffer: the buffer's LDS offset is an immediate
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;
@@ -236,18 +358,88 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                 if (hit_a) sel.offer(da, pos0 + ja, true);
                 sel.offer(db, pos0 + jb, jb < len);
             }
-            for (; j0 < len; j0 += NT) {
+            for (; !AHEAD && j0 < len; j0 += NT) {           // (the pair loop's odd last chunk)
                 const uint32_t j = j0 + lane;
                 const uint4 cn = cp[min(j + NT, len - 1)];
                 const float dis = adc16_halves<B>(cc, dis0, two);
                 sel.offer(dis, pos0 + j, j < len);
                 cc = cn;
             }
+            if (AHEAD) {
+                // cr[C] = this thread's code of trip C, requested one probe ahead; once trip C's gathers are issued the same
+                // registers are reloaded with chunk C of the NEXT list (and, with chunk 0, its row BEHIND the chunk: vmcnt
+                // retires in order, the row must not sit in front of codes needed sooner).  Everything a probe loads is loaded
+                // unconditionally and in one place (behind the last probe the loads re-read the current list's addresses --
+                // prefetch_meta left n_off / n_key alone -- cache hits): the compiler then counts the loads younger than the
+                // one it waits for exactly; with a load under a condition, two load sites for one register, or a copy of a
+                // register with a load in flight it falls back to vmcnt(0) -- a wait for the chunk requested a trip ago.
+                const uint32_t w64 = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64;
+                // a list longer than NPRE chunks: its further chunks first, NEX at a time (requested after the table build; the
+                // visiting order inside a list is as free as the order of the lists: walk_order.cuh)
+                if (hasx) {
+                    for (uint32_t jx = w64x; jx < len; jx += NEX * NT) {
+                        uint4 cur[NEX];
+#pragma unroll
+                        for (int e = 0; e < NEX; e++) cur[e] = ex[e];
+                        if (jx + NEX * NT < len) {
+#pragma unroll
+                            for (int e = 0; e < NEX; e++) ex[e] = cp[min(jx + (NEX + e) * NT + lane, len - 1)];
+                        }
+#pragma unroll
+                        for (int e = 0; e < NEX; e++) {
+                            const uint32_t j0e = jx + e * NT;
+                            if (j0e < len) {
+                                VLQ_PH_TRIP();
+                                const float dis = adc16_halves<B>(cur[e], dis0, two);
+                                sel.offer(dis, pos0 + j0e + lane, j0e + lane < len);
+                            }
+                        }
+                    }
+                }
+                auto trip = [&](auto cc_) {
+                    constexpr int C = decltype(cc_)::value;
+                    const uint32_t jc = w64 + C * NT;
+                    uint32_t g = jc < len ? 1u : 0u;      // (wave-uniform)
+                    float lo[8], hi[8];
+                    if (g && !(VLQ_SCAN16_ABL & 2)) {
+                        VLQ_PH_TRIP();
+                        VLQ_PH_G0();
+                        const uint4 cur = cr[C];
+                        if (B == 0) { { float (&v)[8] = lo; VLQ_G8LO_NW(0, cur.x, cur.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(0, cur.z, cur.w); } }
+                        else { { float (&v)[8] = lo; VLQ_G8LO_NW(16384, cur.x, cur.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(16384, cur.z, cur.w); } }
+                    }
+                    if (!(VLQ_SCAN16_ABL & 16)) load_chunk(cc_);
+                    if (C == 0 && !(VLQ_SCAN16_ABL & 8)) load_rows();
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    asm volatile("" : "+s"(g));        // (keeps the two halves of the trip from being threaded into two copies of the loads)
+                    if (g && (VLQ_SCAN16_ABL & 2)) {
+                        const uint4 cur = cr[C];
+                        if (VLQ_SCAN16_ABL & 1) asm volatile("" :: "v"(cur.x)); else sel.offer(dis0 + __uint_as_float(cur.x & 0x3fffffffu), pos0 + jc + lane, jc + lane < len);
+                    }
+                    if (g && !(VLQ_SCAN16_ABL & 2)) {
+                        float dis = dis0;
+                        VLQ_WAIT8(8, lo);
+#pragma unroll
+                        for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, lo[m]);
+                        asm volatile("" : "+v"(dis));
+                        VLQ_WAIT8(0, hi);
+#pragma unroll
+                        for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hi[m]);
+                        VLQ_PH_G1();
+                        if (VLQ_SCAN16_ABL & 1) asm volatile("" :: "v"(dis));
+                        else sel.offer(dis, pos0 + jc + lane, jc + lane < len);
+                    }
+                };
+                trip(std::integral_constant<int, 0>{});
+                trip(std::integral_constant<int, 1>{});
+                if (NPRE == 3) trip(std::integral_constant<int, 2>{});
+            }
         };
         if (NBUF == 1 || buf == 0) scan_list(std::integral_constant<int, 0>{});
         else scan_list(std::integral_constant<int, 1>{});
         nscan += len;
         if (NBUF == 2) buf ^= 1;
+        VLQ_PH(6);
     }
     if (t == 0) walk_state_finish(a, t_walk, i_end - i_begin, walk_mean);
 
@@ -274,6 +466,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
     }
     if (t == 0) atomicAdd(a.ncode, (unsigned long long)nscan);
     if (badkey) *a.bad_key = 1;
+#ifdef VLQ_SCAN16_PHASES
+    VLQ_PH(7);
+    if (!OWNED && lane == 0 && wave < 2 && (blockIdx.x % 29) == 0) {     // a sample: every workgroup's atomics would be what is measured
+        unsigned long long* o = a.ncode + 8 + 20 * wave;
+#pragma unroll
+        for (int i2 = 0; i2 < 14; i2++) atomicAdd(o + i2, (unsigned long long)ph_[i2]);
+        atomicAdd(o + 14, 1ull);
+        atomicAdd(o + 15, ((unsigned long long)ph_trips_ << 32) | (unsigned long long)(i_end - i_begin));
+        atomicAdd(o + 16, (unsigned long long)(ph_last_ - ph_t0_));
+        atomicAdd(o + 17, (unsigned long long)(wall_clock64() - ph_rt0_));
+        atomicAdd(o + 18, (unsigned long long)ph_g_);
+    }
+#endif
 }
 
 // joins the parts of the list-owned schedule: one wave per query rebuilds the query's probe metadata
@@ -609,7 +814,8 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     size_t lutb = (size_t)2 * 4096 * 4;
     const size_t merge = (size_t)nw * a.k * 8;
     if (lutb < merge) lutb = merge;
-    const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+    const size_t wrec = a.nprobe <= 64 ? (size_t)a.nprobe * 12 + 8 : 0;       // walking-order copies of the probe metadata (scan16_kernel)
+    const size_t tail = (size_t)nw * 64 * 8 * (a.k > 256 ? 4 : 1) + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + wrec;
     const size_t smem = lutb + tail;
     // k <= 64.  Lists of a few hundred codes (mean list < 1024 codes: every BASELINE shape but the long-list tools): ONE table
     // buffer and the plain chunk loop -- 95 VGPRs and 19 KB of LDS = 5 workgroups per CU instead of 4.  Round 4, 10 000
@@ -626,11 +832,16 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
     // queries 0.183 -> 0.202, 1250 queries on G1 0.101 -> 0.116).  VLQ_SCAN16_VARIANT = 4 / 1 force two / four waves.
     if (a.k <= 64 && plain && !a.tail_r && a.nsplit == 1 && (variant == 4 || (variant < 0 && !a.long_lists && a.nq >= 3000))) {
         const size_t l1 = std::max((size_t)4096 * 4, (size_t)2 * a.k * 8);
-        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + wrec;
         launch_scan16_t<1, 2, 1, false>(a, (int)l1, l1 + tail2, s);
     } else if (a.k <= 64 && plain && (variant == 1 || (variant < 0 && !a.long_lists))) {
         const size_t l1 = std::max((size_t)4096 * 4, merge);
         launch_scan16_t<1, 4, 1, false>(a, (int)l1, l1 + tail, s);
+    } else if (a.k <= 64 && variant == 6 && plain && !a.tail_r && a.nsplit == 1) {
+        // two waves AND two table buffers (one barrier per probe; 33 KB of LDS = 4 workgroups per CU)
+        const size_t l2 = std::max((size_t)2 * 4096 * 4, (size_t)2 * a.k * 8);
+        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + wrec;
+        launch_scan16_t<1, 2, 2, false>(a, (int)l2, l2 + tail2, s);
     } else if (a.k <= 64 && variant == 2 && plain) launch_scan16_t<1, 4, 2, false>(a, (int)lutb, smem, s);
     else if (a.k <= 64 && variant == 3 && plain) {
         const size_t l1 = std::max((size_t)4096 * 4, merge);
@@ -640,7 +851,7 @@ void launch_scan16(const ScanArgs& a_in, hipStream_t s) {
         // two waves per workgroup as for k <= 64 (128 VGPRs forced): k = 100, 10 000 queries: headline data 0.815 -> 0.77 ms,
         // nprobe 64 1.34 -> 1.13, G1 0.75 -> 0.68
         const size_t l1 = std::max((size_t)4096 * 4, (size_t)2 * a.k * 8);
-        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64;
+        const size_t tail2 = (size_t)2 * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + wrec;
         launch_scan16_t<2, 2, 1, false>(a, (int)l1, l1 + tail2, s);
     }
     else if (a.k <= 128) {          // recall@100: half the merge network of the 256-key list

@@ -257,6 +257,24 @@ __device__ __forceinline__ float adc16_halves(const uint4 cc, float dis, uint32_
     return dis;
 }
 
+// the same, with `after_issue()` run once both half blocks are issued and the code's registers are dead: a reload of THOSE
+// registers placed there needs no second register set (and no copy at a loop's back edge, whose wait would be for the reload)
+template <int BUF, typename F>
+__device__ __forceinline__ float adc16_halves_then(const uint4 cc, float dis, uint32_t two, F&& after_issue) {
+    float lo[8], hi[8];
+    if (BUF == 0) { { float (&v)[8] = lo; VLQ_G8LO_NW(0, cc.x, cc.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(0, cc.z, cc.w); } }
+    else { { float (&v)[8] = lo; VLQ_G8LO_NW(16384, cc.x, cc.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(16384, cc.z, cc.w); } }
+    after_issue();
+    VLQ_WAIT8(8, lo);
+#pragma unroll
+    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, lo[m]);
+    asm volatile("" : "+v"(dis));
+    VLQ_WAIT8(0, hi);
+#pragma unroll
+    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hi[m]);
+    return dis;
+}
+
 template <int BUF>
 __device__ __forceinline__ float adc16_fixed(const uint4 cc, float dis, uint32_t two) {
     float v[16];
@@ -324,6 +342,27 @@ __device__ __forceinline__ bool probe_meta_fill(const ScanArgs& a, int64_t q, Pr
 // max_codes cut (IndexIVFPQ.cpp:1033: stop after the probe that reaches it); probes behind
 // the cut are marked not visited.  Returns the number of probes visited.
 __device__ __forceinline__ int probe_meta_scan(const ScanArgs& a, ProbeMeta& pm, int lane) {
+    if (a.nprobe <= 64) {
+        // one probe per lane, VALU only (round 5): the cross-lane steps of the general form below are ds_bpermutes, and
+        // under the list scans' gathers each waits hundreds of cycles in the LDS queue -- 18 of them sat between the set-up
+        // barriers of every workgroup.  Lengths are summed as 26 + 6 bit halves (64 x 2^32 < 2^38).
+        const bool in = lane < a.nprobe;
+        const uint32_t len = in ? pm.plen[lane] : 0u;
+        const uint32_t lo = wave_scan_incl_u32(len & 0x3ffffffu), hi = wave_scan_incl_u32(len >> 26);
+        const uint64_t incl = ((uint64_t)hi << 26) + lo;
+        if (in) pm.cum[lane] = (uint32_t)(incl - len);
+        const u64 over = __ballot(in && a.max_codes && incl >= (uint64_t)a.max_codes);
+        const int cut = over ? __builtin_ctzll(over) + 1 : a.nprobe;         // first probe index AFTER the cut
+        if (lane == 63) pm.cum[a.nprobe] = (uint32_t)incl;
+        __builtin_amdgcn_wave_barrier();
+        if (cut < a.nprobe) {
+            const uint32_t endpos = pm.cum[cut];
+            __builtin_amdgcn_wave_barrier();
+            for (int p = cut + lane; p <= a.nprobe; p += 64) pm.cum[p] = endpos;
+            for (int p = cut + lane; p < a.nprobe; p += 64) pm.pkey[p] = -1;
+        }
+        return cut;
+    }
     const int per = (a.nprobe + 63) >> 6;
     const int p0 = lane * per;
     uint64_t local = 0;

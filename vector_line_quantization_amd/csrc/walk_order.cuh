@@ -25,20 +25,66 @@
 
 namespace vlq {
 
+// What the walking order reads from global memory, requested at the top of the kernel (round 5): three dependent-free loads
+// whose latency used to sit between the two set-up barriers (profiles/r05_scan16_phases.txt).
+struct WalkPre {
+    int flag = 0;       // lane < 32: walk_stat_kernel's count of workgroup `lane`
+    int mean_now = 0;   // running mean of the walk time, as read now
+    int dur = 0;        // its value when this launch was prepared: the clock period of every workgroup of the launch
+};
+__device__ __forceinline__ WalkPre walk_prefetch(const ScanArgs& a, int lane) {
+    WalkPre w;
+    if (a.walk_first < 0) return w;
+    if (a.walk_flag && lane < 32) w.flag = a.walk_flag[lane];
+    if (a.walk_state) {
+        w.mean_now = a.walk_state[(blockIdx.x & 7) * 16];
+        // plain accesses: a stale value is as good as a fresh one, and device-scope atomics leave the XCD (measured: +17 %)
+        w.dur = a.walk_state[(blockIdx.x & 7) * 16 + 1];       // the same value for every workgroup of this launch
+    }
+    return w;
+}
+
 // wave 0 of the workgroup, after ord[0 .. nl) holds the live probes in coarse-distance order
 // returns -1 when the coarse-distance order stays, else the running mean of the walk time as read now (0 = none yet): the
 // value walk_state_finish folds this workgroup's own time into
-__device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMeta& pm, uint16_t* ord, int nl, int lane) {
+__device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMeta& pm, uint16_t* ord, int nl, int lane, const WalkPre& pre) {
     const int first = a.walk_first;
     if (first < 0 || nl - first < 2 || nl - first > 256) return -1;
     if (a.walk_flag) {      // walk_stat_kernel: do this batch's neighbours share most of their lists anyway?
-        int v = lane < 32 ? a.walk_flag[lane] : 0;
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        int v = pre.flag;
+        v += (int)lane_xor_u32((uint32_t)v, 16);      // (VALU moves: wave_topk.cuh)
+        v += (int)lane_xor_u32((uint32_t)v, 8);
+        v += (int)lane_xor_u32((uint32_t)v, 4);
+        v += (int)lane_xor_u32((uint32_t)v, 2);
+        v += (int)lane_xor_u32((uint32_t)v, 1);
         if (__builtin_amdgcn_readfirstlane(v) > a.walk_limit) return -1;
     }
     __builtin_amdgcn_wave_barrier();
     const int n = nl - first;
+    // the clock's share of the list ids (both forms below)
+    long long period = a.walk_clock;
+    const int mean_now = a.walk_state ? pre.mean_now : 0;
+    if (period == 0 && a.walk_state) period = (long long)pre.dur * a.walk_scale / 1000;
+    int X = -1;
+    if (period > 0 && period < (1ll << 31)) {
+        // the low 32 bits of the 100 MHz clock (they wrap every 43 s: one odd phase, speed only), 32-bit remainder, the
+        // share of the list ids in float: the 64-bit remainder and quotient by a variable cost two software divisions
+        // between the set-up barriers
+        const uint32_t r = (uint32_t)wall_clock64() % (uint32_t)period;
+        X = (int)(((float)r / (float)(uint32_t)period) * (float)a.nlist);
+    }
+    if (n <= 64 && a.nlist <= (1 << 22)) {
+        // one probe per lane (round 5): a 64-lane sort of (list id, probe) instead of n rounds of v_readlane + compares
+        // (12 600 cycles of every workgroup's set-up on the headline shape, wave 1 waiting at the barrier)
+        const int pr = lane < n ? ord[first + lane] : 0;
+        const uint32_t k32 = lane < n ? (((uint32_t)pm.pkey[pr] << 10) | (uint32_t)pr) : 0xffffffffu;
+        const uint32_t sk = wave_sort64_u32(k32, lane);
+        const int rot = X >= 0 ? __popcll(__ballot(lane < n && (int)(sk >> 10) < X)) : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n) { int pos = lane - rot; if (pos < 0) pos += n; ord[first + pos] = (uint16_t)(sk & 1023u); }
+        __builtin_amdgcn_wave_barrier();
+        return max(mean_now, 0);
+    }
     int p[4], key[4], rank[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -65,16 +111,7 @@ __device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMet
     // the workgroups of an XCD, whenever they started, are near the same id and a row shared by two of them is asked for twice
     // within L2's memory.
     int rot = 0;
-    long long period = a.walk_clock;
-    int mean_now = 0;
-    if (a.walk_state) mean_now = a.walk_state[(blockIdx.x & 7) * 16];
-    if (period == 0 && a.walk_state) {
-        // plain accesses: a stale value is as good as a fresh one, and device-scope atomics leave the XCD (measured: +17 %)
-        const int dur = a.walk_state[(blockIdx.x & 7) * 16 + 1];      // the same value for every workgroup of this launch
-        period = (long long)dur * a.walk_scale / 1000;
-    }
-    if (period > 0) {
-        const int X = (int)((wall_clock64() % (unsigned long long)period) * (unsigned long long)a.nlist / (unsigned long long)period);
+    if (X >= 0) {
 #pragma unroll
         for (int c = 0; c < 4; c++) rot += __popcll(__ballot(lane + 64 * c < n && key[c] < X));
     }
@@ -83,6 +120,9 @@ __device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMet
         if (lane + 64 * c < n) { int pos = rank[c] - rot; if (pos < 0) pos += n; ord[first + pos] = (uint16_t)p[c]; }
     __builtin_amdgcn_wave_barrier();
     return max(mean_now, 0);
+}
+__device__ __forceinline__ int walk_order_sort(const ScanArgs& a, const ProbeMeta& pm, uint16_t* ord, int nl, int lane) {
+    return walk_order_sort(a, pm, ord, nl, lane, walk_prefetch(a, lane));
 }
 
 // thread 0 of a workgroup after its walk: running mean (1/8) of the walk time in clock ticks, per XCD.  `mean` was read at the

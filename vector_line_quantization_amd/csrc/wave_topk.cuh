@@ -95,6 +95,32 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
+// Ascending bitonic sort of 64 32-bit keys, one per lane (VALU only, like the 64-bit one).
+__device__ __forceinline__ uint32_t wave_sort64_u32(uint32_t key, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t other = lane_xor_u32(key, stride);
+            const bool up = (lane & size) == 0;
+            const bool lower = (lane & stride) == 0;
+            key = (lower == up) ? min(key, other) : max(key, other);
+        }
+    }
+    return key;
+}
+
+// Inclusive prefix sum over the 64 lanes, VALU only (DPP row shifts, then the row totals by row_bcast:15 / :31).
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Ascending bitonic sort of 64 keys, one per lane.
 __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
 #pragma unroll
