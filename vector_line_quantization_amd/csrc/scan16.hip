@@ -34,6 +34,8 @@ namespace vlq {
 #ifndef VLQ_SCAN16_ABL
 #define VLQ_SCAN16_ABL 0
 #endif
+static constexpr bool kAblSelect = (VLQ_SCAN16_ABL & 1) != 0, kAblGather = (VLQ_SCAN16_ABL & 2) != 0, kAblStore = (VLQ_SCAN16_ABL & 4) != 0,
+                      kAblRows = (VLQ_SCAN16_ABL & 8) != 0, kAblCodes = (VLQ_SCAN16_ABL & 16) != 0;
 #ifdef VLQ_SCAN16_PHASES
 #define VLQ_PH_DECL                                              \
     uint64_t ph_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
         // loads otherwise queue behind the gathers of the CU's other workgroups (scan 0.665 ->
         // 0.655 ms at the headline shape; levels 1..3 measure the same)
         __builtin_amdgcn_s_setprio(2);
-        if (VLQ_SCAN16_ABL & 4) {
+        if (kAblStore) {
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) asm volatile("" :: "v"(t2r[i2].x), "v"(t2r[i2].y), "v"(t2r[i2].z), "v"(t2r[i2].w));
         } else build_lut16<NI>(L, t, t2r, m2t3);
@@ -401,22 +403,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                     const uint32_t jc = w64 + C * NT;
                     uint32_t g = jc < len ? 1u : 0u;      // (wave-uniform)
                     float lo[8], hi[8];
-                    if (g && !(VLQ_SCAN16_ABL & 2)) {
+                    if (g && !kAblGather) {
                         VLQ_PH_TRIP();
                         VLQ_PH_G0();
                         const uint4 cur = cr[C];
                         if (B == 0) { { float (&v)[8] = lo; VLQ_G8LO_NW(0, cur.x, cur.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(0, cur.z, cur.w); } }
                         else { { float (&v)[8] = lo; VLQ_G8LO_NW(16384, cur.x, cur.y); } { float (&v)[8] = hi; VLQ_G8HI_NW(16384, cur.z, cur.w); } }
                     }
-                    if (!(VLQ_SCAN16_ABL & 16)) load_chunk(cc_);
-                    if (C == 0 && !(VLQ_SCAN16_ABL & 8)) load_rows();
+                    if (!kAblCodes) load_chunk(cc_);
+                    if (C == 0 && !kAblRows) load_rows();
                     g = __builtin_amdgcn_readfirstlane(g);
                     asm volatile("" : "+s"(g));        // (keeps the two halves of the trip from being threaded into two copies of the loads)
-                    if (g && (VLQ_SCAN16_ABL & 2)) {
+                    if (g && kAblGather) {
                         const uint4 cur = cr[C];
-                        if (VLQ_SCAN16_ABL & 1) asm volatile("" :: "v"(cur.x)); else sel.offer(dis0 + __uint_as_float(cur.x & 0x3fffffffu), pos0 + jc + lane, jc + lane < len);
+                        if (kAblSelect) asm volatile("" :: "v"(cur.x)); else sel.offer(dis0 + __uint_as_float(cur.x & 0x3fffffffu), pos0 + jc + lane, jc + lane < len);
                     }
-                    if (g && !(VLQ_SCAN16_ABL & 2)) {
+                    if (g && !kAblGather) {
                         float dis = dis0;
                         VLQ_WAIT8(8, lo);
 #pragma unroll
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
 #pragma unroll
                         for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hi[m]);
                         VLQ_PH_G1();
-                        if (VLQ_SCAN16_ABL & 1) asm volatile("" :: "v"(dis));
+                        if (kAblSelect) asm volatile("" :: "v"(dis));
                         else sel.offer(dis, pos0 + jc + lane, jc + lane < len);
                     }
                 };
