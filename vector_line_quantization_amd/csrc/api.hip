@@ -229,14 +229,14 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
             TRY(h->ws_kept.reserve(16));
             HIP_TRY(hipMemsetAsync(h->ws_kept.p, 0, 16, h->stream));
         }
-        TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
-        if (h->nlist > 8192) TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 64) * sizeof(float)));
+        TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n, h->nlist)));
+        if (h->nlist > 8192 || vlq::coarse_screen_matrix_free_ok(h->nlist, nprobe)) TRY(h->ws_tmin.reserve((size_t)n * (h->nlist / 16 + 32) * sizeof(float)));
         TRY(h->ws_qn_c.reserve((size_t)n * sizeof(float)));
         vlq::launch_screen_prep(x_dev, h->screen.mu.as<float>(), n, h->d, h->screen.scale, h->ws_xh.p, h->ws_qn.as<float>(),
                                 h->ws_qn_c.as<float>(), h->ws_xflags.as<unsigned char>(), h->stream);
         vlq::launch_coarse_screened(x_dev, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), h->coarse.as<float>(), h->screen.half.p,
                                     h->ws_qn.as<float>(), h->cnorm.as<float>(), h->ws_qn_c.as<float>(), h->screen.norm_c.as<float>(),
-                                    h->ws_dist.as<float>(), h->nlist > 8192 ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, h->nlist,
+                                    h->ws_dist.as<float>(), h->ws_tmin.p ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, h->nlist,
                                     h->d, nprobe, h->screen.scale, h->screen.cmax, h->screen.cmax0, cdis_dev, keys_dev,
                                     h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
                                     h->stream);
@@ -332,14 +332,14 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
             TRY(h->ws_xflags.reserve((size_t)n));
             TRY(h->ws_qn.reserve((size_t)n * 4));
             TRY(h->ws_qn_c.reserve((size_t)n * 4));
-            TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n)));
-            if (kc > 8192) TRY(h->ws_tmin.reserve((size_t)n * (kc / 64) * sizeof(float)));
+            TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n, kc)));
+            if (kc > 8192 || vlq::coarse_screen_matrix_free_ok(kc, T)) TRY(h->ws_tmin.reserve((size_t)n * (kc / 16 + 32) * sizeof(float)));
             vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
             vlq::launch_screen_prep(sub, sc.mu.as<float>(), n, dc, sc.scale, h->ws_xh.p, h->ws_qn.as<float>(), h->ws_qn_c.as<float>(),
                                     h->ws_xflags.as<unsigned char>(), h->stream);
             vlq::launch_coarse_screened(sub, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), cent, sc.half.p, h->ws_qn.as<float>(),
                                         h->imi_norm.as<float>() + (size_t)m * kc, h->ws_qn_c.as<float>(), sc.norm_c.as<float>(), tab[m],
-                                        kc > 8192 ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
+                                        h->ws_tmin.p ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
                                         h->ws_screen_cnt.as<unsigned int>(), h->stream);
             TRY(screen_counters_copy(h, n));
             continue;

@@ -46,6 +46,7 @@ namespace vlq {
 namespace {
 
 #define FLT_MAX_F 3.402823466e+38f
+__device__ __forceinline__ uint32_t f32_to_ordered_inv(uint32_t u) { return __float_as_uint(ordered_to_f32(u)); }
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -54,11 +55,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // components 16 ks + 8 h .. + 7 = one 16-byte load): no LDS, no barrier.  The kernel is bound by the matrix it writes.
 // tmin != nullptr (rows wider than 8192 columns): also the minimum of every 64-column tile of a row, [nq][nlist / 64];
 // out == nullptr: ONLY those minima, in fp32 (the 1-NN screen of the assignment).
-template <int KS>
+// BITS (the matrix-free screen, round 5): no matrix and no minima -- one bit per element, "approximate distance <= trow[row]",
+// bits[row][col / 32]: a wave's ballot over a register of the accumulator is 32 columns of two rows, so every (row, 32-column)
+// word is written whole by one wave, no atomics.  5 MB instead of the 82 MB half matrix at 10 000 x 4096.
+template <int KS, bool BITS = false>
 __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                               const float* __restrict__ qn, const float* __restrict__ cn,
                                                               _Float16* __restrict__ out, int64_t nq, int nlist, float inv_s2,
-                                                              float sd, float* __restrict__ tmin) {
+                                                              float sd, float* __restrict__ tmin, const float* __restrict__ trow = nullptr,
+                                                              uint32_t* __restrict__ bits = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + (wave >> 1) * 64;
@@ -86,6 +91,42 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
             const int64_t row = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             qnr[rb][reg] = qn[row < nq ? row : nq - 1];
         }
+    if (BITS) {
+        // the same approximate distance as the minima pass (identical operations: a column at the row's cut passes its own
+        // test); lane L of wq[rb] collects the word of (row L >> 1 of the block, 32-column half L & 1)
+        const int nw = nlist >> 5;
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            float tr[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t row = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                tr[reg] = trow[row < nq ? row : nq - 1];
+            }
+            uint32_t wq = 0;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                f32x16 acc;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][ks], b[cb][ks], acc, 0, 0, 0);
+                const float cnv = cn[col0 + cb * 32 + r];
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const float v = __fsub_rn(__fadd_rn(qnr[rb][reg], cnv), __fmul_rn(2.f, __fmul_rn(acc[reg], inv_s2)));
+                    const u64 m = __ballot(v <= tr[reg]);          // (false for NaN)
+                    const int rl = (reg & 3) + 8 * (reg >> 2);     // row of the lower half wave; the upper half's is rl + 4
+                    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);         // (wave-uniform: scalar registers)
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wq) : "s"(mlo), "n"(2 * rl + cb));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wq) : "s"(mhi), "n"(2 * (rl + 4) + cb));
+                }
+            }
+            const int64_t row = row0 + rb * 32 + (lane >> 1);
+            if (row < nq) bits[row * nw + (col0 >> 5) + (lane & 1)] = wq;
+        }
+        return;
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
@@ -150,6 +191,161 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
                     if (row < nq) tmin[row * ntile + (col0 >> 6)] = out ? (float)(_Float16)__fmul_rn(sd, tmv[rb][g]) : tmv[rb][g];
                 }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The matrix-free screen's two passes (round 5).  A wave owns 32 queries and a RANGE of 32 x NB centroids: the queries'
+// operand stays in registers, the centroid blocks stream past it (next block requested while the current one multiplies);
+// the four waves of a workgroup take four query blocks against the same range, so a centroid block is fetched from L2 once
+// per workgroup.  Rounds 3-4's kernel gave a wave one 64 x 64 tile: 32 KB of operands per 4096 products, 640 MB of L2 reads
+// at 10 000 x 4096 -- that, not the matrix it wrote, was what it was bound by (37 us with nothing written).
+// The product is taken TRANSPOSED (centroids as the MFMA's rows): lane (n, h) then holds 16 centroids of ONE query n, so
+//   pass 0 keeps a running minimum per (lane, register) over the range's blocks -- the row's pool for the bound: class
+//          m = centroid mod 32 of every range, [nq][32 x ranges] -- 1 fma + 1 min per product, nothing across lanes;
+//   pass 1 sets a bit per product under the row's bound, 16 per lane, the two halves' bits joined into the (query, block)
+//          word, transposed through LDS into bits[row][col / 32].
+// The approximate distance is a = qn_c + v', v' = fma(-2 / s^2, ip~, cn_c); both passes compute v' by the same operation, the
+// bound kernel adds qn_c (monotone: the nprobe-th smallest class minimum of v' gives the nprobe-th smallest of a) and hands
+// pass 1 the bound minus qn_c, rounded up.
+#ifndef VLQ_STREAM_ABL
+#define VLQ_STREAM_ABL 0          // timing experiments (wrong results): 1 no epilogue, 2 no MFMA, 4 no stage copies, 8 no LDS fragment reads
+#endif
+template <int KS, int PASS>
+__global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
+                                                                   const float* __restrict__ cn, int64_t nq, int nlist, int nb_range,
+                                                                   float m2_inv_s2, float* __restrict__ pool, int npool,
+                                                                   const float* __restrict__ tsub, uint32_t* __restrict__ bits) {
+    // The centroid blocks reach the four waves through LDS: stages of SB blocks in a ring of RING buffers, filled by LDS-DMA
+    // (global_load_lds_dwordx4: a wave instruction moves 1 KB, no registers) three stages ahead -- every wave issues a quarter
+    // of a stage (a linear copy: the operand order keeps a stage's blocks contiguous), waits for its own share of the stage
+    // that is due (vmcnt: the two later stages stay in flight) and meets the others at ONE barrier per stage.  Measured on the
+    // way here (10 000 x 4096, d = 128, per pass): every wave fetching its own blocks from L2 25-30 us whatever the prefetch
+    // depth (4 x the bytes: L2 bandwidth); through LDS with register staging one stage ahead 22-27 us (a stage's loads, ~1.5 us
+    // from L2 under load, against 0.7 us of multiplies).
+    constexpr int SB = 2;                         // blocks per stage
+    constexpr int RING = 3;
+    constexpr int AHEAD = 2;
+    constexpr int NBR = 32;                       // blocks per range at most (the launch's nb_range)
+    constexpr int PT = (SB * KS + 3) / 4;         // 1 KB pieces per wave and stage (the last may run past the stage: clamped)
+    constexpr int STAGE = SB * KS * 64;           // 16-byte elements per stage
+    __shared__ __attribute__((aligned(16))) h16x8 cl[RING][PT * 256];
+    __shared__ uint32_t wt[PASS == 1 ? 4 : 1][32][NBR + 1];       // pass 1: [wave][query][block of the range] (padded)
+    __shared__ __attribute__((aligned(16))) float cnl[NBR * 32];  // the range's centroid norms
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t rb = (int64_t)blockIdx.x * 4 + wave;            // query block of 32 (rows past nq: the operand's zero padding)
+    const int range = blockIdx.y;
+    const int cb0 = range * nb_range;                             // first centroid block of 32
+    const int nblk = nlist >> 5;
+    const int nb = min(nb_range, nblk - cb0);                     // >= 1 by the launch's grid
+    const h16x8* cbase = reinterpret_cast<const h16x8*>(Ch) + (int64_t)cb0 * (KS * 64);
+    const int nel = nb * KS * 64;                                 // 16-byte elements of the range
+    // every stage is PT instructions per wave, past the range's end too (the last element again, into a buffer nobody reads):
+    // the count in flight at a wait is then a constant
+    auto stage_issue = [&](int st) __attribute__((always_inline)) {
+        const int buf = st % RING;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const int e = min(st * STAGE + i * 256 + (int)threadIdx.x, nel - 1);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(cbase + e),
+                                             (void __attribute__((address_space(3)))*)(&cl[buf][i * 256 + wave * 64]), 16, 0, 0);
+        }
+    };
+    // set-up loads first (older than every stage: a wait for them never waits for a stage)
+    h16x8 qf[KS];
+    {
+        const h16x8* src = reinterpret_cast<const h16x8*>(Qh) + rb * (KS * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[ks] = src[ks * 64];
+    }
+    const int64_t row = rb * 32 + n;
+    float tv = 0.f;
+    if (PASS == 1) tv = tsub[row < nq ? row : nq - 1];
+    float cnr[(NBR * 32 + 255) / 256];
+#pragma unroll
+    for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnr[i] = cn[(int64_t)cb0 * 32 + min(i * 256 + (int)threadIdx.x, nb * 32 - 1)];
+    stage_issue(0);
+    stage_issue(1);
+#pragma unroll
+    for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnl[i * 256 + threadIdx.x] = cnr[i];
+    float mn[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) mn[r] = FLT_MAX_F;
+    const int nst = (nb + SB - 1) / SB;
+    // pass 1's bound, one ulp up: v <= tsub  <=>  v - nextup(tsub) < 0 (the sign bit is what is collected)
+    const float tvu = __uint_as_float(f32_to_ordered_inv(f32_to_ordered(tv) + 1u));
+    for (int st = 0; st < nst; st++) {
+        const int buf = st % RING;
+        // this wave's share of stage st has landed (stage st + 1 may still be in flight), then everybody's; the
+        // barrier also says that everybody is done with stage st - 1, whose buffer the next issue refills
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (((AHEAD - 1) * PT) & 15) | (((((AHEAD - 1) * PT) >> 4) & 3) << 14));
+        __syncthreads();
+        stage_issue(st + AHEAD);
+        f32x16 acc[SB];
+#pragma unroll
+        for (int p = 0; p < SB; p++) {
+            // (ds_read by hand: a compiler-visible LDS load behind an LDS-DMA gets a vmcnt(0) in front -- a wait for the
+            // stages just requested.  What orders these reads behind their stage is the counted wait + barrier above.)
+            h16x8 cf[KS];
+            const uint32_t la = (uint32_t)(uintptr_t)(&cl[buf][p * KS * 64 + lane]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cf[ks]) : "v"(la), "n"(ks * 1024));
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                // fragment ks is back when at most KS - 1 - ks of the later reads are outstanding
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cf[ks]) : "n"(KS - 1 - ks));
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], qf[ks], acc[p], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < SB; p++) {
+            const int bb = st * SB + p;
+            if (bb >= nb) break;                                  // (wave-uniform; a block past the range multiplied a repeat)
+            const float* cp = cnl + bb * 32 + 4 * h;              // the norms of this lane's 16 centroids 8 g + 4 h + i
+            uint32_t w = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 c4v = *reinterpret_cast<const float4*>(cp + 8 * g);
+                const float c4[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float v = __fmaf_rn(m2_inv_s2, acc[p][4 * g + i], c4[i]);
+                    if (PASS == 0) mn[4 * g + i] = fminf(mn[4 * g + i], v);            // (a NaN never becomes a minimum)
+                    else {
+                        // one more bit from the top: (w << 1) | sign(v - bound); centroid 8 g + 4 h + i ends at bit 15 - (4 g + i).
+                        // (A NaN may set its bit: a column kept for nothing, the exact stage decides.)
+                        const uint32_t t = __float_as_uint(__fsub_rn(v, tvu));
+                        w = __builtin_amdgcn_alignbit(w, t, 31);
+                    }
+                }
+            }
+            if (PASS == 1) {
+                // this half's 16 bits | the other half's << 16: bit 16 h' + 15 - (4 g + i) of the word = centroid 8 g + 4 h' + i
+                const uint32_t o = lane_xor_u32(w, 32);
+                if (h == 0) wt[wave][n][bb] = w | (o << 16);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the repeats issued past the range's end
+    __syncthreads();
+    if (PASS == 1) {
+        // the range's words of 32 queries: out as contiguous bytes per query (the loop's last barrier ordered the words)
+        const int nw = nlist >> 5;
+        if (row < nq) {
+            uint32_t* dst = bits + row * nw + cb0 + (NBR / 2) * h;
+#pragma unroll
+            for (int j = 0; j < NBR / 2; j++)
+                if ((NBR / 2) * h + j < nb) dst[j] = wt[wave][n][(NBR / 2) * h + j];
+        }
+    }
+    if (PASS == 0 && row < nq) {
+        float* dst = pool + row * npool + range * 32 + 4 * h;     // class m = 8 g + 4 h + i of this range
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(mn[4 * g], mn[4 * g + 1], mn[4 * g + 2], mn[4 * g + 3]);
     }
 }
 
@@ -431,6 +627,64 @@ __global__ __launch_bounds__(256) void coarse_screen_keep_tiled_kernel(const _Fl
     }
 }
 
+// The matrix-free screen's bound (round 5): one wave per row reads the row's 64-column tile minima (fp32, from the minima pass:
+// every tile minimum is a distinct column's value, so the nprobe-th smallest of them bounds the row's nprobe-th smallest element
+// from above) and leaves trow[row] = the largest approximate distance a column may have and still be kept -- -FLT_MAX for a row
+// the bound cannot decide (rflag[row] = 1: the exact kernel does the whole row).  MT = tile minima per lane (ntile <= 64 MT).
+template <int MT>
+__global__ __launch_bounds__(256) void coarse_screen_cut_kernel(const float* __restrict__ pool, int64_t nq, int npool, int nprobe,
+                                                                const float* __restrict__ qn, const float* __restrict__ qn0,
+                                                                const unsigned char* __restrict__ flags, float cmax, float cmax0, float c_sub,
+                                                                float* __restrict__ tsub, unsigned char* __restrict__ rflag) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const float* pq = pool + q * npool;
+    float mt[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) { const int t = i * 64 + lane; mt[i] = t < npool ? pq[t] : FLT_MAX_F; }
+    // nprobe-th smallest class minimum of v' (distinct columns): only the VALUE is needed -- 32-bit sorts and merges of the
+    // ordered images (nprobe <= 64: the answer is among the 64 smallest)
+    uint32_t sk[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) sk[i] = wave_sort64_u32(f32_to_ordered(mt[i]), lane);
+    // the 64 smallest of two ascending lists: elementwise min against the other list reversed (a bitonic sequence), re-sorted
+    auto lo64 = [&](uint32_t x, uint32_t o) __attribute__((always_inline)) {
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x140, 0xF, 0xF, true);      // row_mirror
+        o = lane_xor_u32(lane_xor_u32(o, 16), 32);
+        uint32_t v = min(x, o);
+        { const uint32_t t = lane_xor_u32(v, 32); v = (lane & 32) == 0 ? min(v, t) : max(v, t); }
+        { const uint32_t t = lane_xor_u32(v, 16); v = (lane & 16) == 0 ? min(v, t) : max(v, t); }
+        { const uint32_t t = lane_xor_u32(v, 8); v = (lane & 8) == 0 ? min(v, t) : max(v, t); }
+        { const uint32_t t = lane_xor_u32(v, 4); v = (lane & 4) == 0 ? min(v, t) : max(v, t); }
+        { const uint32_t t = lane_xor_u32(v, 2); v = (lane & 2) == 0 ? min(v, t) : max(v, t); }
+        { const uint32_t t = lane_xor_u32(v, 1); v = (lane & 1) == 0 ? min(v, t) : max(v, t); }
+        return v;
+    };
+    if constexpr (MT >= 2) {
+#pragma unroll
+        for (int i = 0; i < MT; i += 2) sk[i] = lo64(sk[i], sk[i + 1]);
+    }
+    if constexpr (MT >= 4) {
+#pragma unroll
+        for (int i = 0; i < MT; i += 4) sk[i] = lo64(sk[i], sk[i + 2]);
+    }
+    if constexpr (MT >= 8) {
+#pragma unroll
+        for (int i = 0; i < MT; i += 8) sk[i] = lo64(sk[i], sk[i + 4]);
+    }
+    if constexpr (MT >= 16) sk[0] = lo64(sk[0], sk[8]);
+    const float cutv = ordered_to_f32((uint32_t)__builtin_amdgcn_readlane((int)sk[0], nprobe - 1));
+    const float qc = qn[q];
+    const float cut = __fadd_rn(qc, cutv);                        // ... of the approximate distances a = qn_c + v' (monotone)
+    bool finite;
+    const float T = screen_threshold(cut, qc, qn0[q], cmax, cmax0, c_sub, 1.f, &finite);      // (fp32 values: sd = 1)
+    const bool undecided = !finite || flags[q] || !(cutv < FLT_MAX_F);
+    // v' > tsub  =>  fl(qn_c + v') > T: the difference rounded up by more than the two roundings can lose
+    const float ts = __fadd_rn(__fsub_rn(T, qc), __fmul_rn(4.8e-7f /* 2^-21 */, __fadd_rn(fabsf(T), fabsf(qc))));
+    if (lane == 0) { tsub[q] = undecided ? -FLT_MAX_F : ts; rflag[q] = undecided ? 1 : 0; }
+}
+
 // <q, c_col> for up to 64 columns at once, lane l for column col_of(l) (l < ncand), as the f32 MFMA kernel accumulates it: an
 // fmaf chain over k = 0, 1, 2, ...  The centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's
 // 64-byte piece (a lane reading its own row would touch 64 cache lines per load instruction), the owner reads its row back
@@ -489,13 +743,18 @@ __device__ __forceinline__ float exact_ip_batch(const float* __restrict__ Cn, in
 // centroid rows come in through LDS, 16 components at a time: 4 lanes fetch one row's 64-byte piece (a lane reading
 // its own row would touch 64 cache lines per load instruction), the owner reads its row back component by component
 // (rows padded to 20 floats: 16-byte LDS accesses both ways); the next chunk's pieces are requested before the current one is used.
-template <int KPL>
+// BITS: the kept columns come as the row's bitmap (bits[q][nlist / 32], the matrix-free screen) with rflag[q] = "whole row";
+// `keep` / `nkeep` are then unused.
+template <int KPL, bool BITS = false>
 __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t* __restrict__ keep, const uint16_t* __restrict__ nkeep,
                                                                   int64_t nq, int nlist, int nprobe, float* __restrict__ cdis,
                                                                   int64_t* __restrict__ keys, const float* __restrict__ Q,
                                                                   const float* __restrict__ Cn, const float* __restrict__ qn,
                                                                   const float* __restrict__ cn, int d,
-                                                                  unsigned long long* __restrict__ kept_total) {
+                                                                  unsigned long long* __restrict__ kept_total,
+                                                                  const uint32_t* __restrict__ bits = nullptr,
+                                                                  const unsigned char* __restrict__ rflag = nullptr,
+                                                                  unsigned int* __restrict__ exact_rows = nullptr) {
     __shared__ u64 queue[4][64];
     __shared__ uint32_t cand[4][kKeepCap];
     __shared__ __attribute__((aligned(16))) float qrow[4][128];
@@ -504,21 +763,53 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= nq) return;                        // whole wave; no workgroup barrier below
     // one round trip for everything the row needs first: the count, the whole (fixed-size) list, the query, its norm
-    const int nk = nkeep[q];
-    uint32_t kc[kKeepCap / 64];
-#pragma unroll
-    for (int u = 0; u < kKeepCap / 64; u++) kc[u] = keep[q * kKeepCap + u * 64 + lane];
     const float q0 = lane < d ? Q[q * d + lane] : 0.f, q1 = lane + 64 < d ? Q[q * d + lane + 64] : 0.f;
     const float qnv = qn[q];
-    const bool exact_row = nk == 0xffff;
-    const int total = exact_row ? 0 : nk;
+    bool exact_row;
+    int total;
+    if (BITS) {
+        // the row's bitmap -> column list in LDS (ascending columns): 64 words per step, positions by a prefix sum of the popcounts
+        const int nw = nlist >> 5;
+        const uint32_t* bq = bits + q * nw;
+        const bool whole = rflag[q] != 0;
+        int tot = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t word = (w < nw && !whole) ? bq[w] : 0u;
+            const uint32_t c = (uint32_t)__popc(word);
+            const uint32_t incl = wave_scan_incl_u32(c);
+            uint32_t pos = (uint32_t)tot + incl - c;
+            while (word) {
+                const int bpos = __ffs(word) - 1;
+                // (the stream kernel's bit order: bit 16 h + 15 - (4 g + i) is column 8 g + 4 h + i of the word's 32)
+                const uint32_t k15 = 15u - ((uint32_t)bpos & 15u), hh = (uint32_t)bpos >> 4;
+                if (pos < (uint32_t)kKeepCap) cand[wave][pos] = (uint32_t)w * 32u + 8u * (k15 >> 2) + 4u * hh + (k15 & 3u);
+                pos++;
+                word &= word - 1u;
+            }
+            tot += (int)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        exact_row = whole || tot > kKeepCap || tot < nprobe;
+        total = exact_row ? 0 : tot;
+        if (exact_row && exact_rows && lane == 0) atomicAdd(exact_rows, 1u);
+    } else {
+        const int nk = nkeep[q];
+        uint32_t kc[kKeepCap / 64];
 #pragma unroll
-    for (int u = 0; u < kKeepCap / 64; u++) cand[wave][u * 64 + lane] = kc[u];
+        for (int u = 0; u < kKeepCap / 64; u++) kc[u] = keep[q * kKeepCap + u * 64 + lane];
+        exact_row = nk == 0xffff;
+        total = exact_row ? 0 : nk;
+#pragma unroll
+        for (int u = 0; u < kKeepCap / 64; u++) cand[wave][u * 64 + lane] = kc[u];
+    }
     qrow[wave][lane] = q0;
     qrow[wave][lane + 64] = q1;
     WaveSelect<KPL> sel;
     sel.init(nprobe, queue[wave], lane);
     __builtin_amdgcn_wave_barrier();
+#ifdef VLQ_EXACT_PROLOGUE_ONLY
+    if (total >= 0) { if (lane == 0) cdis[q * nprobe] = (float)total; return; }
+#endif
     if (!exact_row) {
         float* st = stage[wave];
         for (int c0 = 0; c0 < total; c0 += 64) {
@@ -638,7 +929,17 @@ void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float
                        (d + 15) / 16, scale, reinterpret_cast<_Float16*>(out_half), norms, norms_c, flags);
 }
 
-size_t coarse_screen_keep_bytes(int64_t nq) { return (size_t)nq * (kKeepCap * sizeof(uint32_t) + sizeof(uint16_t)); }
+// keep_ws: the kept-column lists of the matrix path, or -- matrix-free -- the rows' bitmaps, bounds and flags
+size_t coarse_screen_keep_bytes(int64_t nq, int nlist) {
+    const size_t lists = (size_t)nq * (kKeepCap * sizeof(uint32_t) + sizeof(uint16_t));
+    const size_t free_ = (size_t)nq * ((size_t)(nlist >> 5) * 4 + 4 + 1) + 64;
+    return std::max(lists, free_);
+}
+// the matrix-free form serves 64 <= nlist / 64 tiles <= 256 per row (the bound's pool) and nprobe <= 64
+bool coarse_screen_matrix_free_ok(int nlist, int nprobe) {
+    static const bool off = getenv("VLQ_COARSE_MATRIX") != nullptr;      // A/B: the half matrix of rounds 3-4
+    return !off && nlist >= 1024 && nlist <= 16384 && nprobe <= 64 && nprobe * 2 <= 32 * (((nlist >> 5) + 31) / 32);
+}
 
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
                             const float* qn, const float* cn, const float* qn_c, const float* cn_c,
@@ -658,6 +959,43 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
     const _Float16* qh = reinterpret_cast<const _Float16*>(q_half);
     const _Float16* ch = reinterpret_cast<const _Float16*>(c_half);
     dim3 grid((unsigned)((nq + 127) / 128), (unsigned)((nlist + 127) / 128));
+    if (tmin_ws && coarse_screen_matrix_free_ok(nlist, nprobe)) {
+        // Matrix-free (round 5): (1) the approximate distances' 64-column tile minima, fp32, nothing else stored; (2) per row
+        // the bound from the nprobe-th smallest tile minimum; (3) the approximate distances once more -- 4 us of f16 MFMA --
+        // leaving one bit per element under the bound; (4) the exact stage on the marked columns.  Rounds 3-4 wrote the
+        // matrix as halves and read it back: 82 MB each way at 10 000 x 4096, which is what both kernels were bound by.
+        const float c_sub = 1.220703125e-04f /* 2^-13 */ * sqrtf((float)d) / scale * 1.001f;
+        char* wsb = reinterpret_cast<char*>(keep_ws);
+        uint32_t* bits = reinterpret_cast<uint32_t*>(wsb);
+        float* trow = reinterpret_cast<float*>(wsb + (((size_t)nq * (nlist >> 5) * 4 + 15) & ~(size_t)15));
+        unsigned char* rflag = reinterpret_cast<unsigned char*>(trow + nq);
+        // a range = 32 blocks of 32 centroids (1024 columns); the bound's pool = 32 classes per range
+        const int nb_range = 32;
+        const int nranges = ((nlist >> 5) + nb_range - 1) / nb_range;
+        const int npool = 32 * nranges;
+        float* pool = tmin_ws;                                     // [nq][npool]  (npool <= nlist / 64 * 2: the caller sized it for nlist / 64 floats ... x 2 below)
+        dim3 sgridq((unsigned)((nq + 127) / 128), (unsigned)nranges);
+        const float m2 = -2.f * inv_s2;
+#define VLQ_STR0(K) hipLaunchKernelGGL((coarse_f16_stream_kernel<K, 0>), sgridq, dim3(256), 0, s, qh, ch, cn_c, nq, nlist, nb_range, m2, pool, npool, \
+                                       (const float*)nullptr, (uint32_t*)nullptr)
+#define VLQ_STR1(K) hipLaunchKernelGGL((coarse_f16_stream_kernel<K, 1>), sgridq, dim3(256), 0, s, qh, ch, cn_c, nq, nlist, nb_range, m2, (float*)nullptr, npool, \
+                                       (const float*)trow, bits)
+#define VLQ_KS(M) switch (ks) { case 1: M(1); break; case 2: M(2); break; case 3: M(3); break; case 4: M(4); break; case 5: M(5); break; \
+                                case 6: M(6); break; case 7: M(7); break; default: M(8); break; }
+        VLQ_KS(VLQ_STR0)
+        dim3 sgrid((unsigned)((nq + 3) / 4)), block(256);
+#define VLQ_CUT(MT) hipLaunchKernelGGL(coarse_screen_cut_kernel<MT>, sgrid, block, 0, s, pool, nq, npool, nprobe, qn_c, qn, q_flags, cmax, cmax0, \
+                                       c_sub, trow, rflag)
+        if (npool <= 64) VLQ_CUT(1); else if (npool <= 128) VLQ_CUT(2); else if (npool <= 256) VLQ_CUT(4); else if (npool <= 512) VLQ_CUT(8); else VLQ_CUT(16);
+        VLQ_KS(VLQ_STR1)
+        hipLaunchKernelGGL((coarse_screen_exact_kernel<1, true>), sgrid, block, 0, s, (const uint32_t*)nullptr, (const uint16_t*)nullptr, nq, nlist,
+                           nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows);
+#undef VLQ_STR0
+#undef VLQ_STR1
+#undef VLQ_KS
+#undef VLQ_CUT
+        return;
+    }
     float* tmin = nlist > 8192 ? tmin_ws : nullptr;
 #define VLQ_F16G(K) hipLaunchKernelGGL(coarse_f16_dist_kernel<K>, grid, dim3(256), 0, s, qh, ch, qn_c, cn_c, ah, nq, nlist, inv_s2, sd, tmin)
     switch (ks) {

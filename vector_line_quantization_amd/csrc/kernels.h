@@ -45,7 +45,8 @@ void launch_coarse_screened_nn(const float* q, const void* q_half, const unsigne
                                const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* tmin_ws, int64_t nq, int nlist,
                                int d, float scale, float cmax, float cmax0, float* cdis, int64_t* keys, unsigned int* exact_rows,
                                hipStream_t s);
-size_t coarse_screen_keep_bytes(int64_t nq);      // keep_ws of launch_coarse_screened
+size_t coarse_screen_keep_bytes(int64_t nq, int nlist);      // keep_ws of launch_coarse_screened
+bool coarse_screen_matrix_free_ok(int nlist, int nprobe);    // the screen without the half matrix (tmin_ws then always needed)
 // qn / cn: exact squared norms (reference order) of queries / centroids; qn_c / cn_c: of the centred ones; cmax = max |c - mu|
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
                             const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* approx,
