@@ -223,22 +223,27 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
     // way here (10 000 x 4096, d = 128, per pass): every wave fetching its own blocks from L2 25-30 us whatever the prefetch
     // depth (4 x the bytes: L2 bandwidth); through LDS with register staging one stage ahead 22-27 us (a stage's loads, ~1.5 us
     // from L2 under load, against 0.7 us of multiplies).
+    // A wave multiplies QW = 2 query blocks (64 queries) against every centroid block: the bytes that must be in flight to
+    // cover the ~1.5 us a stage takes from L2 are halved -- with one query block per wave the loop waited for its stages
+    // (22-27 us per pass in every variant of the staging).
     constexpr int SB = 2;                         // blocks per stage
     constexpr int RING = 3;
     constexpr int AHEAD = 2;
-    constexpr int NBR = 32;                       // blocks per range at most (the launch's nb_range)
+    constexpr int QW = 2;                         // query blocks per wave
+    constexpr int NBR = 16;                       // blocks per range at most (the launch's nb_range)
     constexpr int PT = (SB * KS + 3) / 4;         // 1 KB pieces per wave and stage (the last may run past the stage: clamped)
     constexpr int STAGE = SB * KS * 64;           // 16-byte elements per stage
     __shared__ __attribute__((aligned(16))) h16x8 cl[RING][PT * 256];
-    __shared__ uint32_t wt[PASS == 1 ? 4 : 1][32][NBR + 1];       // pass 1: [wave][query][block of the range] (padded)
+    __shared__ uint32_t wt[PASS == 1 ? 4 * QW : 1][32][NBR + 1];  // pass 1: [wave, query block][query][block of the range] (padded)
     __shared__ __attribute__((aligned(16))) float cnl[NBR * 32];  // the range's centroid norms
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
-    const int64_t rb = (int64_t)blockIdx.x * 4 + wave;            // query block of 32 (rows past nq: the operand's zero padding)
+    const int64_t nrb = (nq + 127) / 128 * 4;                     // query blocks of 32 the half copy holds (zero rows past nq)
+    const int64_t rb0 = ((int64_t)blockIdx.x * 4 + wave) * QW;    // this wave's first query block
     const int range = blockIdx.y;
     const int cb0 = range * nb_range;                             // first centroid block of 32
     const int nblk = nlist >> 5;
-    const int nb = min(nb_range, nblk - cb0);                     // >= 1 by the launch's grid
+    const int nb = min(nb_range, nblk - cb0);                     // >= 1 by the launch's grid; even (nlist % 64 == 0, nb_range even)
     const h16x8* cbase = reinterpret_cast<const h16x8*>(Ch) + (int64_t)cb0 * (KS * 64);
     const int nel = nb * KS * 64;                                 // 16-byte elements of the range
     // every stage is PT instructions per wave, past the range's end too (the last element again, into a buffer nobody reads):
@@ -253,15 +258,23 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
         }
     };
     // set-up loads first (older than every stage: a wait for them never waits for a stage)
-    h16x8 qf[KS];
-    {
-        const h16x8* src = reinterpret_cast<const h16x8*>(Qh) + rb * (KS * 64) + lane;
+    h16x8 qf[QW][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) qf[ks] = src[ks * 64];
+    for (int qb = 0; qb < QW; qb++) {
+        const h16x8* src = reinterpret_cast<const h16x8*>(Qh) + min(rb0 + qb, nrb - 1) * (KS * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[qb][ks] = src[ks * 64];
     }
-    const int64_t row = rb * 32 + n;
-    float tv = 0.f;
-    if (PASS == 1) tv = tsub[row < nq ? row : nq - 1];
+    float tvu[QW];                                // pass 1's bound, one ulp up: v <= tsub  <=>  v - nextup(tsub) < 0 (the sign bit is collected)
+#pragma unroll
+    for (int qb = 0; qb < QW; qb++) {
+        tvu[qb] = 0.f;
+        if (PASS == 1) {
+            const int64_t r_ = (rb0 + qb) * 32 + n;
+            const float tv = tsub[r_ < nq ? r_ : nq - 1];
+            tvu[qb] = __uint_as_float(f32_to_ordered_inv(f32_to_ordered(tv) + 1u));
+        }
+    }
     float cnr[(NBR * 32 + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnr[i] = cn[(int64_t)cb0 * 32 + min(i * 256 + (int)threadIdx.x, nb * 32 - 1)];
@@ -269,12 +282,12 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
     stage_issue(1);
 #pragma unroll
     for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnl[i * 256 + threadIdx.x] = cnr[i];
-    float mn[16];
+    float mn[QW][16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) mn[r] = FLT_MAX_F;
-    const int nst = (nb + SB - 1) / SB;
-    // pass 1's bound, one ulp up: v <= tsub  <=>  v - nextup(tsub) < 0 (the sign bit is what is collected)
-    const float tvu = __uint_as_float(f32_to_ordered_inv(f32_to_ordered(tv) + 1u));
+    for (int qb = 0; qb < QW; qb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mn[qb][r] = FLT_MAX_F;
+    const int nst = nb / SB;
     for (int st = 0; st < nst; st++) {
         const int buf = st % RING;
         // this wave's share of stage st has landed (stage st + 1 may still be in flight), then everybody's; the
@@ -282,70 +295,75 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
         __builtin_amdgcn_s_waitcnt(0x0F70 | (((AHEAD - 1) * PT) & 15) | (((((AHEAD - 1) * PT) >> 4) & 3) << 14));
         __syncthreads();
         stage_issue(st + AHEAD);
-        f32x16 acc[SB];
 #pragma unroll
         for (int p = 0; p < SB; p++) {
+            const int bb = st * SB + p;
             // (ds_read by hand: a compiler-visible LDS load behind an LDS-DMA gets a vmcnt(0) in front -- a wait for the
             // stages just requested.  What orders these reads behind their stage is the counted wait + barrier above.)
             h16x8 cf[KS];
             const uint32_t la = (uint32_t)(uintptr_t)(&cl[buf][p * KS * 64 + lane]);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cf[ks]) : "v"(la), "n"(ks * 1024));
+            f32x16 acc[QW];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+            for (int qb = 0; qb < QW; qb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[qb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 // fragment ks is back when at most KS - 1 - ks of the later reads are outstanding
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cf[ks]) : "n"(KS - 1 - ks));
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], qf[ks], acc[p], 0, 0, 0);
-            }
-        }
 #pragma unroll
-        for (int p = 0; p < SB; p++) {
-            const int bb = st * SB + p;
-            if (bb >= nb) break;                                  // (wave-uniform; a block past the range multiplied a repeat)
+                for (int qb = 0; qb < QW; qb++) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[ks], qf[qb][ks], acc[qb], 0, 0, 0);
+            }
             const float* cp = cnl + bb * 32 + 4 * h;              // the norms of this lane's 16 centroids 8 g + 4 h + i
-            uint32_t w = 0;
+            float c16[16];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const float4 c4v = *reinterpret_cast<const float4*>(cp + 8 * g);
-                const float c4[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+                c16[4 * g] = c4v.x; c16[4 * g + 1] = c4v.y; c16[4 * g + 2] = c4v.z; c16[4 * g + 3] = c4v.w;
+            }
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float v = __fmaf_rn(m2_inv_s2, acc[p][4 * g + i], c4[i]);
-                    if (PASS == 0) mn[4 * g + i] = fminf(mn[4 * g + i], v);            // (a NaN never becomes a minimum)
+            for (int qb = 0; qb < QW; qb++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = __fmaf_rn(m2_inv_s2, acc[qb][r], c16[r]);
+                    if (PASS == 0) mn[qb][r] = fminf(mn[qb][r], v);                    // (a NaN never becomes a minimum)
                     else {
-                        // one more bit from the top: (w << 1) | sign(v - bound); centroid 8 g + 4 h + i ends at bit 15 - (4 g + i).
-                        // (A NaN may set its bit: a column kept for nothing, the exact stage decides.)
-                        const uint32_t t = __float_as_uint(__fsub_rn(v, tvu));
+                        // one more bit from the top: (w << 1) | sign(v - bound); centroid 8 g + 4 h + i (r = 4 g + i) ends at
+                        // bit 15 - r.  (A NaN may set its bit: a column kept for nothing, the exact stage decides.)
+                        const uint32_t t = __float_as_uint(__fsub_rn(v, tvu[qb]));
                         w = __builtin_amdgcn_alignbit(w, t, 31);
                     }
                 }
-            }
-            if (PASS == 1) {
-                // this half's 16 bits | the other half's << 16: bit 16 h' + 15 - (4 g + i) of the word = centroid 8 g + 4 h' + i
-                const uint32_t o = lane_xor_u32(w, 32);
-                if (h == 0) wt[wave][n][bb] = w | (o << 16);
+                if (PASS == 1) {
+                    // this half's 16 bits | the other half's << 16: bit 16 h' + 15 - (4 g + i) of the word = centroid 8 g + 4 h' + i
+                    const uint32_t o = lane_xor_u32(w, 32);
+                    if (h == 0) wt[wave * QW + qb][n][bb] = w | (o << 16);
+                }
             }
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the repeats issued past the range's end
     __syncthreads();
-    if (PASS == 1) {
-        // the range's words of 32 queries: out as contiguous bytes per query (the loop's last barrier ordered the words)
-        const int nw = nlist >> 5;
-        if (row < nq) {
+#pragma unroll
+    for (int qb = 0; qb < QW; qb++) {
+        const int64_t row = (rb0 + qb) * 32 + n;
+        if (row >= nq) continue;
+        if (PASS == 1) {
+            // the range's words of 32 queries: out as contiguous bytes per query
+            const int nw = nlist >> 5;
             uint32_t* dst = bits + row * nw + cb0 + (NBR / 2) * h;
 #pragma unroll
             for (int j = 0; j < NBR / 2; j++)
-                if ((NBR / 2) * h + j < nb) dst[j] = wt[wave][n][(NBR / 2) * h + j];
-        }
-    }
-    if (PASS == 0 && row < nq) {
-        float* dst = pool + row * npool + range * 32 + 4 * h;     // class m = 8 g + 4 h + i of this range
+                if ((NBR / 2) * h + j < nb) dst[j] = wt[wave * QW + qb][n][(NBR / 2) * h + j];
+        } else {
+            float* dst = pool + row * npool + range * 32 + 4 * h;     // class m = 8 g + 4 h + i of this range
 #pragma unroll
-        for (int g = 0; g < 4; g++)
-            *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(mn[4 * g], mn[4 * g + 1], mn[4 * g + 2], mn[4 * g + 3]);
+            for (int g = 0; g < 4; g++)
+                *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(mn[qb][4 * g], mn[qb][4 * g + 1], mn[qb][4 * g + 2], mn[qb][4 * g + 3]);
+        }
     }
 }
 
@@ -645,9 +663,23 @@ __global__ __launch_bounds__(256) void coarse_screen_cut_kernel(const float* __r
     for (int i = 0; i < MT; i++) { const int t = i * 64 + lane; mt[i] = t < npool ? pq[t] : FLT_MAX_F; }
     // nprobe-th smallest class minimum of v' (distinct columns): only the VALUE is needed -- 32-bit sorts and merges of the
     // ordered images (nprobe <= 64: the answer is among the 64 smallest)
-    uint32_t sk[MT];
+    // (more than two values per lane: the lane's two smallest stand for them -- still distinct columns' values, and the sorting
+    // network, which is what this kernel's time is, stays at two registers)
+    constexpr int SK = MT >= 2 ? 2 : 1;
+    uint32_t sk[SK];
+    {
+        uint32_t a = f32_to_ordered(mt[0]), b2 = MT >= 2 ? f32_to_ordered(mt[MT >= 2 ? 1 : 0]) : 0xffffffffu;
+        if (MT >= 2) { const uint32_t lo = min(a, b2), hi = max(a, b2); a = lo; b2 = hi; }
 #pragma unroll
-    for (int i = 0; i < MT; i++) sk[i] = wave_sort64_u32(f32_to_ordered(mt[i]), lane);
+        for (int i = 2; i < MT; i++) {
+            const uint32_t x = f32_to_ordered(mt[i]);
+            const uint32_t t = max(a, x);
+            a = min(a, x);
+            b2 = min(b2, t);
+        }
+        sk[0] = wave_sort64_u32(a, lane);
+        if (MT >= 2) sk[SK - 1] = wave_sort64_u32(b2, lane);
+    }
     // the 64 smallest of two ascending lists: elementwise min against the other list reversed (a bitonic sequence), re-sorted
     auto lo64 = [&](uint32_t x, uint32_t o) __attribute__((always_inline)) {
         o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x140, 0xF, 0xF, true);      // row_mirror
@@ -661,19 +693,7 @@ __global__ __launch_bounds__(256) void coarse_screen_cut_kernel(const float* __r
         { const uint32_t t = lane_xor_u32(v, 1); v = (lane & 1) == 0 ? min(v, t) : max(v, t); }
         return v;
     };
-    if constexpr (MT >= 2) {
-#pragma unroll
-        for (int i = 0; i < MT; i += 2) sk[i] = lo64(sk[i], sk[i + 1]);
-    }
-    if constexpr (MT >= 4) {
-#pragma unroll
-        for (int i = 0; i < MT; i += 4) sk[i] = lo64(sk[i], sk[i + 2]);
-    }
-    if constexpr (MT >= 8) {
-#pragma unroll
-        for (int i = 0; i < MT; i += 8) sk[i] = lo64(sk[i], sk[i + 4]);
-    }
-    if constexpr (MT >= 16) sk[0] = lo64(sk[0], sk[8]);
+    if (MT >= 2) sk[0] = lo64(sk[0], sk[SK - 1]);
     const float cutv = ordered_to_f32((uint32_t)__builtin_amdgcn_readlane((int)sk[0], nprobe - 1));
     const float qc = qn[q];
     const float cut = __fadd_rn(qc, cutv);                        // ... of the approximate distances a = qn_c + v' (monotone)
@@ -938,7 +958,7 @@ size_t coarse_screen_keep_bytes(int64_t nq, int nlist) {
 // the matrix-free form serves 64 <= nlist / 64 tiles <= 256 per row (the bound's pool) and nprobe <= 64
 bool coarse_screen_matrix_free_ok(int nlist, int nprobe) {
     static const bool off = getenv("VLQ_COARSE_MATRIX") != nullptr;      // A/B: the half matrix of rounds 3-4
-    return !off && nlist >= 1024 && nlist <= 16384 && nprobe <= 64 && nprobe * 2 <= 32 * (((nlist >> 5) + 31) / 32);
+    return !off && nlist >= 1024 && nlist <= 16384 && nprobe <= 64 && nprobe * 2 <= 32 * (((nlist >> 5) + 15) / 16);
 }
 
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
@@ -969,12 +989,12 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
         uint32_t* bits = reinterpret_cast<uint32_t*>(wsb);
         float* trow = reinterpret_cast<float*>(wsb + (((size_t)nq * (nlist >> 5) * 4 + 15) & ~(size_t)15));
         unsigned char* rflag = reinterpret_cast<unsigned char*>(trow + nq);
-        // a range = 32 blocks of 32 centroids (1024 columns); the bound's pool = 32 classes per range
-        const int nb_range = 32;
+        // a range = 16 blocks of 32 centroids (512 columns); the bound's pool = 32 classes per range
+        const int nb_range = 16;
         const int nranges = ((nlist >> 5) + nb_range - 1) / nb_range;
         const int npool = 32 * nranges;
         float* pool = tmin_ws;                                     // [nq][npool]  (npool <= nlist / 64 * 2: the caller sized it for nlist / 64 floats ... x 2 below)
-        dim3 sgridq((unsigned)((nq + 127) / 128), (unsigned)nranges);
+        dim3 sgridq((unsigned)((nq + 255) / 256), (unsigned)nranges);      // a workgroup = 4 waves x 64 queries
         const float m2 = -2.f * inv_s2;
 #define VLQ_STR0(K) hipLaunchKernelGGL((coarse_f16_stream_kernel<K, 0>), sgridq, dim3(256), 0, s, qh, ch, cn_c, nq, nlist, nb_range, m2, pool, npool, \
                                        (const float*)nullptr, (uint32_t*)nullptr)
