@@ -194,6 +194,15 @@ int vlq_ivfpq_get_precomputed_table(vlq_ivfpq_t h, float* out);
 /* indexIVFPQ_stats (IndexIVFPQ.h:169-195): codes visited since the last reset. */
 int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset);
 
+/* Introspection, speed only (replaces nothing in the reference): what the last search's list scan was -- the kernel shape
+ * chosen for the batch, the walking order of a query's probes (csrc/walk_order.cuh: decided on the device from the lists
+ * neighbouring queries share) and the clock period the walk ran with -- as text:
+ *   "kernel=scan16_kernel<1, 2, 1, false, false, false> order=list-id walk first=1 shared=123/8192 limit=2457 period_ticks=9876".
+ * Synchronises the stream.  vlq_ivfpq_reset_walk_state forgets the measured walk times: the next search runs as the first
+ * search of a fresh handle does (what a driver that calls search once gets; bench.py's cold_walk_ms). */
+int vlq_ivfpq_last_scan_info(vlq_ivfpq_t h, char* buf, int cap);
+int vlq_ivfpq_reset_walk_state(vlq_ivfpq_t h);
+
 /* HIP-event timing of the stages of the search calls issued since the last
  * reset, on the index's stream: ms[0]=coarse (norms+GEMM+select), ms[1]=query
  * tables, ms[2]=list scan (+top-k), calls = number of timed scan launches.

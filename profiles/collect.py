@@ -106,6 +106,10 @@ sys.path.insert(0, os.path.dirname(HERE))
 import bench
 out["sources_sha256"] = bench.sources_sha()
 # ... and the same setting of the data generator (bench.py defaults at the time of the passes)
-out["generator"] = [0.005, 12, 0.4] if R >= "r04" else list(bench.G1_FLAGS)
+# ... taken from what bench.py recorded in that run (rounds before 5 did not record it: their defaults)
+try:
+    out["generator"] = json.load(open(dst("bench.json")))["dataset"]["generator_flags"]
+except Exception:
+    out["generator"] = [0.005, 12, 0.4] if R >= "r04" else list(bench.G1_FLAGS)
 json.dump(out, open(dst("scan_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -18,7 +18,7 @@ SYMBOLS = [
     "vlq_ivfpq_ntotal", "vlq_ivfpq_list_length", "vlq_ivfpq_get_list", "vlq_ivfpq_search",
     "vlq_ivfpq_search_preassigned", "vlq_ivfpq_coarse_search", "vlq_ivfpq_query_tables",
     "vlq_ivfpq_get_precomputed_table", "vlq_ivfpq_stats", "vlq_ivfpq_profile",
-    "vlq_ivfpq_profile_read", "vlq_merge_topk",
+    "vlq_ivfpq_profile_read", "vlq_merge_topk", "vlq_ivfpq_last_scan_info", "vlq_ivfpq_reset_walk_state",
     # include/vlq_line.h
     "vlq_line_set_float16_tables", "vlq_line_set_row_mode", "vlq_line_set_scan_parts", "vlq_line_create", "vlq_line_destroy", "vlq_line_set_stream", "vlq_line_set_coarse_centroids",
     "vlq_line_set_pq_centroids", "vlq_line_set_lambda_codebook", "vlq_line_set_graph",

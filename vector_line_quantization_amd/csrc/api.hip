@@ -478,6 +478,11 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         // the statistic is computed with the scan order (launch_query_order); behind the order's ni entries: its 32 counts
         const bool walk_auto = wf_env < -1 && a.walk_first >= 0;
         auto walk_part = [&]() -> int* { return walk_auto ? h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3) : nullptr; };
+        // a launch with no measured walk time seeds its clock period from a model (walk_stat_kernel): the workgroups that will
+        // share the chip = the scan kernels' slots (scan16.hip: 2048 two-wave / 1280 four-wave workgroups), at most the batch
+        vlq::WalkSeed wseed;
+        wseed.list_off = h->list_off.as<int64_t>(); wseed.list_len = h->list_len.as<int64_t>(); wseed.nlist = h->nlist;
+        wseed.slots = (int)std::min<int64_t>(ni, (k <= 128 && ni >= 3000 && h->ntotal < (int64_t)h->nlist * 1024) ? 2048 : (k <= 64 ? 1280 : 1024));
         auto walk_decide = [&]() {        // after launch_query_order
             if (!walk_auto || !a.qorder) return;
             static const int share_max = [] { const char* e = getenv("VLQ_WALK_SHARE"); return e ? atoi(e) : 300; }();
@@ -605,7 +610,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -669,6 +674,9 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 }
             }
             tm.stop();
+            snprintf(h->last_scan, sizeof(h->last_scan), "%s", vlq::last_scan16_shape());
+            h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit; h->last_walk_flag = a.walk_flag;
+            h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
         } else if ((vlq::scanm_supports(a) || vlq::scanm0_supports(a)) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
             // 8 / 32 / 64-byte codes: the engineered organisation (scanm.hip); queries ordered like the 16-byte path
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
@@ -676,7 +684,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -1298,6 +1306,41 @@ int vlq_ivfpq_stats(vlq_ivfpq_t h, uint64_t* nq, uint64_t* ncode, int reset) {
     }
     // the reference aborts the search on an out-of-range key (IndexIVFPQ.cpp:1008-1011)
     if (bad) return bad_flag_error(bad);
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_last_scan_info(vlq_ivfpq_t h, char* buf, int cap) {
+    if (!h || !buf || cap < 1) return fail(VLQ_ERR_INVALID, "null argument");
+    TRY(set_dev(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const char* order = "coarse-distance order";
+    int shared = -1;
+    if (h->last_walk_first >= 0) {
+        order = "list-id walk";
+        if (h->last_walk_flag) {        // decided on the device from walk_stat_kernel's counts
+            int v[32];
+            HIP_TRY(hipMemcpy(v, h->last_walk_flag, sizeof(v), hipMemcpyDeviceToHost));
+            shared = 0;
+            for (int x : v) shared += x;
+            if (shared > h->last_walk_limit) order = "coarse-distance order";
+        }
+    }
+    int period = 0, launch_period = 0;      // XCD 0: the running mean of the measured walk times / what the last launch ran with
+    if (h->walk_state.p) {
+        int ws[8 * 16];
+        HIP_TRY(hipMemcpy(ws, h->walk_state.p, sizeof(ws), hipMemcpyDeviceToHost));
+        period = ws[0]; launch_period = ws[1];
+    }
+    snprintf(buf, (size_t)cap, "kernel=%s order=%s first=%d shared=%d/%d limit=%d period_ticks=%d launch_period_ticks=%d",
+             h->last_scan[0] ? h->last_scan : "none", order, h->last_walk_first, shared, h->last_walk_samples, h->last_walk_limit, period,
+             launch_period);
+    return VLQ_OK;
+}
+
+int vlq_ivfpq_reset_walk_state(vlq_ivfpq_t h) {
+    if (!h) return fail(VLQ_ERR_INVALID, "null handle");
+    TRY(set_dev(h));
+    if (h->walk_state.p) HIP_TRY(hipMemsetAsync(h->walk_state.p, 0, 8 * 16 * sizeof(int), h->stream));
     return VLQ_OK;
 }
 

@@ -140,6 +140,11 @@ struct vlq_ivfpq_s {
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
         ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin, walk_state;
     int64_t walk_key = -1;       // (nprobe, k, batch class) the walk times in walk_state were measured for
+    // what the last search_dev scan launch was (vlq_ivfpq_last_scan_info): kernel shape, the walking-order rule and the
+    // device-side statistic it was decided from (32 counts behind the scan order)
+    char last_scan[64] = "";
+    int last_walk_first = -1, last_walk_limit = 0, last_walk_samples = 0;
+    const int* last_walk_flag = nullptr;
     // float16 look-up tables of the plain IVFPQ scan (vlq_ivfpq_set_float16_tables): half(term2), per-page half(term3)
     bool fp16_tables = false, term2h_valid = false;
     DevBuf term2h, ws_qtabh;

@@ -162,6 +162,8 @@ bool scanm0_supports(const ScanArgs& a);      // table mode 0, 8- / 16-byte code
 void launch_scanm(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
+const char* last_scan16_shape();      // "scan16_kernel<KPL, NW, NBUF, PIPE, IMI, OWNED>" of this thread's last launch
+const char* last_scan16_shape();      // "scan16_kernel<KPL, NW, NBUF, PIPE, IMI, OWNED>" of this thread's last launch
 // list-owned schedule of the same kernel: launch_owned_order prepares own_order / own_count / part_mask,
 // launch_qtab16 the per-query table (-2 <q_m, cent_mj>, [nq][16][256]), launch_scan16_owned scans the
 // (query, partition) items and launch_owned_merge writes the final rows
@@ -197,10 +199,15 @@ inline size_t query_order_bins_padded(int nlist) {
     return (nbins + 63) & ~(size_t)63;
 }
 // samples neighbour pairs of the scan order and decides the walking order of the probes (scan16.hip, walk_order.cuh)
-int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s);
+// what a launch without measured walk times seeds its clock period from (walk_order.cuh): the list lengths of the sampled probes
+// and the workgroups that will run side by side
+struct WalkSeed { const int64_t* list_off = nullptr; const int64_t* list_len = nullptr; int nlist = 0; int slots = 0; };
+int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s,
+                     WalkSeed seed = WalkSeed());
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank = nullptr, int* walk_part = nullptr, int* walk_state = nullptr);
+                        int* qorder, hipStream_t s, const int* list_rank = nullptr, int* walk_part = nullptr, int* walk_state = nullptr,
+                        WalkSeed seed = WalkSeed());
 // walk_part (optional): the walking-order statistic (32 counts, see launch_walk_stat) is computed along with the order
 int walk_stat_samples(int64_t nq, int nprobe);
 

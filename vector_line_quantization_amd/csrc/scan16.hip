@@ -14,6 +14,7 @@
 //     query's probes in the spatial order of their lists as well was measured and does not
 //     pay: the nearest lists must come first to tighten the admission threshold.)
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -779,8 +780,14 @@ static void launch_scan16_i(const ScanArgs& a, int lut_region, size_t smem, hipS
     const unsigned grid = (unsigned)(8 * a.grid_per_xcd);
     hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE, IMI>), dim3(grid), dim3(64 * NW), smem, s, a, lut_region);
 }
+// the shape of the last scan16 launch of this thread (vlq_ivfpq_last_scan_info: tests pin the default path with it)
+static thread_local char g_last_scan16[64] = "";
+const char* last_scan16_shape() { return g_last_scan16; }
+
 template <int KPL, int NW, int NBUF, bool PIPE>
 static void launch_scan16_t(const ScanArgs& a, int lut_region, size_t smem, hipStream_t s) {
+    snprintf(g_last_scan16, sizeof(g_last_scan16), "scan16_kernel<%d, %d, %d, %s, %s, %s>", KPL, NW, NBUF, PIPE ? "true" : "false",
+             a.imi_nbits > 0 ? "true" : "false", a.part_keys ? "true" : "false");
     if (a.part_keys) {        // list-owned schedule: 8 x nq slots, the surplus exits at once
         ensure_dynamic_lds(reinterpret_cast<const void*>(scan16_kernel<KPL, NW, NBUF, PIPE, false, true>), smem);
         hipLaunchKernelGGL((scan16_kernel<KPL, NW, NBUF, PIPE, false, true>), dim3((unsigned)(8 * a.nq)), dim3(64 * NW), smem, s,
@@ -969,7 +976,7 @@ __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __re
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state) {
+                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state, WalkSeed seed) {
     if (nq <= 0) return;
     // at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
     // by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
@@ -982,7 +989,7 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
         hipLaunchKernelGGL(qorder_single_kernel, dim3(1), dim3(1024), smem1, s, keys, (int)nq, nprobe, nlist, qorder, list_rank,
                            shift, nbins);
         // (the statistic inside this one-workgroup kernel was measured: 8192 samples on one CU cost 36 us against 5)
-        if (walk_part && nq >= 2) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s);
+        if (walk_part && nq >= 2) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
         return;
     }
     const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
@@ -994,7 +1001,7 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
     ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
     hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
                        hist + stride, qorder, list_rank, shift, nbins);
-    if (walk_part) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s);
+    if (walk_part) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
 }
 
 // ---------------------------------------------------------------------------
@@ -1006,11 +1013,44 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
 // and the scan kernels add the 32 counts up themselves (walk_order_sort): no atomics, no zeroing, no host round trip.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restrict__ keys, const int* __restrict__ qorder, int nq,
-                                                        int nprobe, int pairs, int* __restrict__ part, int* __restrict__ walk_state) {
+                                                        int nprobe, int pairs, int* __restrict__ part, int* __restrict__ walk_state,
+                                                        WalkSeed seed) {
     __shared__ int red[4];
-    // this launch's clock period per XCD = the running mean of the walk times measured so far (walk_order.cuh)
-    if (walk_state && blockIdx.x == 0 && threadIdx.x < 8) walk_state[threadIdx.x * 16 + 1] = walk_state[threadIdx.x * 16];
+    __shared__ unsigned long long lsum[4];
+    __shared__ int lcnt[4];
     const int t = threadIdx.x;
+    // this launch's clock period per XCD = the running mean of the walk times measured so far (walk_order.cuh) -- or, before
+    // anything was measured (the first search of a handle: what a driver that calls search once gets), a MODEL of it: a walk is
+    // nprobe probes, each costing the chip c0 + c1 x (codes of the list) while `slots` workgroups share it:
+    //     period [10 ns ticks] = 0.75 x nprobe x slots x (1.36 ns + 0.0008 ns x mean list length) / 10
+    // (fitted to the two bench data sets: 1.63 ns per probe at 330 codes, 1.92 at 700; a period 20-50 % off costs 1-4 % of
+    // what the right one gains, no period at all costs 20 %: profiles/r05_cold_path.txt).  The lengths are those of block 0's
+    // 256 sampled probes.
+    if (walk_state && blockIdx.x == 0) {
+        unsigned long long len = 0;
+        int ok = 0;
+        if (seed.slots > 0 && seed.list_off) {
+            const int np = min(nprobe, 32), pair = t >> 5, i = t & 31;
+            if (pair < pairs && i < np) {
+                const int s0 = (int)((int64_t)pair * (nq - 1) / pairs);
+                const int64_t x = keys[(int64_t)qorder[s0] * nprobe + i];
+                if (x >= 0 && x < seed.nlist) { len = (unsigned long long)(seed.list_len ? seed.list_len[x] : seed.list_off[x + 1] - seed.list_off[x]); ok = 1; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { len += __shfl_down(len, off); ok += __shfl_down(ok, off); }
+        if ((t & 63) == 0) { lsum[t >> 6] = len; lcnt[t >> 6] = ok; }
+        __syncthreads();
+        if (t < 8) {
+            const int mean = walk_state[t * 16];
+            int period = mean;
+            const int n_ok = lcnt[0] + lcnt[1] + lcnt[2] + lcnt[3];
+            if (mean <= 0 && seed.slots > 0 && n_ok > 0) {
+                const float mean_len = (float)(lsum[0] + lsum[1] + lsum[2] + lsum[3]) / (float)n_ok;
+                period = (int)(0.075f * (float)nprobe * (float)seed.slots * (1.36f + 0.0008f * mean_len));
+            }
+            walk_state[t * 16 + 1] = period;
+        }
+    }
     int shared = walk_stat_sample(keys, qorder, nq, nprobe, pairs, blockIdx.x * 8 + (t >> 5), t & 31);
     for (int off = 32; off > 0; off >>= 1) shared += __shfl_down(shared, off);
     if ((t & 63) == 0) red[t >> 6] = shared;
@@ -1021,9 +1061,9 @@ __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restric
 // returns the number of (pair, probe) samples behind the 32 counts in part[]
 int walk_stat_samples(int64_t nq, int nprobe) { return (int)std::min<int64_t>(256, nq - 1) * std::min(nprobe, 32); }
 
-int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s) {
+int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int nprobe, int* part, int* walk_state, hipStream_t s, WalkSeed seed) {
     const int pairs = (int)std::min<int64_t>(256, nq - 1);
-    hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part, walk_state);
+    hipLaunchKernelGGL(walk_stat_kernel, dim3(32), dim3(256), 0, s, keys, qorder, (int)nq, nprobe, pairs, part, walk_state, seed);
     return pairs * std::min(nprobe, 32);
 }
 

@@ -224,6 +224,15 @@ class GpuIVFPQ:
         check(lib().vlq_ivfpq_stats(self._h, C.byref(nq), C.byref(ncode), C.c_int(int(reset))))
         return nq.value, ncode.value
 
+    def last_scan_info(self):
+        """what the last search's list scan was (kernel shape, walking order, clock period): include/vlq_ivfpq.h"""
+        buf = C.create_string_buffer(256)
+        check(lib().vlq_ivfpq_last_scan_info(self._h, buf, C.c_int(256)))
+        return buf.value.decode()
+
+    def reset_walk_state(self):
+        check(lib().vlq_ivfpq_reset_walk_state(self._h))
+
     def profile(self, enable=True):
         """0 / False: off; 1 / True: every stage; 2: the scan kernel only (two event records per call);
         3: the scan kernel of every 4th call, starting with the next one"""
