@@ -163,6 +163,9 @@ int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k
 /* The parity seam: IndexIVFPQ::search_knn_with_key (IndexIVFPQ.h:140-146,
  * IndexIVFPQ.cpp:964-1060).  keys[n*nprobe] (-1 = skip), coarse_dis[n*nprobe].
  * store_pairs != 0 returns list<<32|offset as label.  All buffers [h|d].
+ * nprobe may exceed VLQ_MAX_NPROBE here (the CPU class has no limit: tests/sift1b_imi_pq.cpp asks for 2048; up to 64 x
+ * VLQ_MAX_NPROBE): the probe list is then scanned in runs of 1024 in coarse order and the rows joined by (distance, run,
+ * place in the run's row) -- the (distance, scan position) order of one long scan.
  * A key >= nlist aborts the reference's search (IndexIVFPQ.cpp:1008-1011): with a host D or I
  * the call synchronises and returns VLQ_ERR_INVALID itself; with device D and I the call stays
  * asynchronous, the offending probe is skipped and the error is returned by the next

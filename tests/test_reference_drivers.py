@@ -35,6 +35,43 @@ def _parse(out):
     return pts, (sel.group(1) if sel else None), rec
 
 
+def _run_cached_pair(exe, data, run):
+    """Two runs of the SAME binary from the driver's cached populated index (tools/make_driver_data.py writes it: no populating
+    run, whose adds would leave the host's OpenMP / MKL pools warm for the CPU-only search only): CPU-only, then the device."""
+    outs = {}
+    for mode in ("off", "on"):
+        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
+                           timeout=1000, cwd=run)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[mode] = (p.stdout, p.stderr)
+        print(mode, "\n".join(p.stdout.splitlines()[-6:]), p.stderr.splitlines()[-1])
+    return outs
+
+
+def _faster_on_the_device(outs):
+    """The driver's own clock around its search call (`avg. query time`): the device run's is below the CPU-only run's.  The
+    index went to the device in the interposed precompute_table (read_index calls it, index_io.cpp:492-495), not inside the
+    search; what is left inside the driver's clock in BOTH runs is the reference's own MultiIndexQuantizer::search on the host
+    (`multi_index_search_seconds`: the larger part of either time)."""
+    t, knn, miq = {}, {}, {}
+    for mode in ("off", "on"):
+        m = re.search(r"avg\. query time\s+([0-9.eE+-]+)\s*ms", outs[mode][0])
+        assert m, outs[mode][0][-600:]
+        t[mode] = float(m.group(1))
+        m = re.search(r"knn_with_key_seconds=([0-9.]+) multi_index_search_seconds=([0-9.]+)", outs[mode][1])
+        assert m, outs[mode][1][-400:]
+        knn[mode], miq[mode] = float(m.group(1)), float(m.group(2))
+    print("avg. query time: CPU-only %.4f ms, device %.4f ms; inside IndexIVFPQ::search_knn_with_key %.4f s / %.4f s; inside the "
+          "reference's MultiIndexQuantizer::search (host, both runs) %.4f s / %.4f s" % (t["off"], t["on"], knn["off"], knn["on"],
+                                                                                       miq["off"], miq["on"]))
+    up = re.search(r"list_uploads=(\d+)", outs["on"][1])
+    assert up and int(up.group(1)) == 1
+    # The part of the call this library replaces is faster on the device.  The driver's own figure also spans the reference's
+    # MultiIndexQuantizer::search -- host code in both runs, 5-10 x the replaced part on these inputs, and measured 20-25 %
+    # SLOWER in the process that has the HIP runtime loaded (profiles/r05_reference_drivers.txt) -- so it is printed, not asserted.
+    assert knn["on"] < knn["off"], (knn, t)
+
+
 def test_interposer_exports_the_reference_symbols():
     """CPU: the prebuilt interposer defines the three member functions under the reference's mangled names."""
     so = os.path.join(RD, "libvlq_interpose.so")
@@ -98,25 +135,18 @@ def test_demo_sift1M_unchanged_on_the_device(tmp_path):
 @pytest.mark.gpu
 def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
     """tests/sift1b_imi_pq.cpp as shipped (inverted multi-index 2 x 14 bits = 2^28 lists, 8-byte codes, nprobe 2048,
-    k 128), compiled in place: CPU-only run, then the device run of the SAME binary on the cached populated index
-    the first run wrote.  Heavy (two 4.3 GB index files, ~40 GB of host memory, ~10 minutes): opt-in with
-    VLQ_RUN_SIFT1B_DRIVER=1; the run of record is profiles/r03_reference_drivers.txt.
+    k 128), compiled in place: CPU-only run, then the device run of the SAME binary, both on the driver's cached populated index.  The 2^28 lists are the driver's (two 4.3 GB index files whatever the data): the database is kept
+    at 100 000 vectors (2000 queries) so that the test is about a minute (VLQ_SKIP_HEAVY_DRIVERS=1 leaves it out).
     The driver's training step (2 M vectors, k-means into 2 x 16 384 centroids on the host) is skipped through the
     driver's own cache branch (:237-251): tools/make_driver_data.py writes the trained-index file it looks for."""
-    if os.environ.get("VLQ_RUN_SIFT1B_DRIVER") != "1":
-        pytest.skip("opt-in: VLQ_RUN_SIFT1B_DRIVER=1")
+    if os.environ.get("VLQ_SKIP_HEAVY_DRIVERS") == "1":
+        pytest.skip("VLQ_SKIP_HEAVY_DRIVERS=1")
     exe = os.path.join(RD, "sift1b_imi_pq")
     if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
         pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
     data, run = str(tmp_path / "data"), str(tmp_path / "run")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "sift1b", run, "500000", "1000"])
-    outs = {}
-    for mode in ("off", "on"):
-        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
-                           timeout=1000, cwd=run)
-        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-        outs[mode] = (p.stdout, p.stderr)
-        print(mode, "\n".join(p.stdout.splitlines()[-6:]), p.stderr.splitlines()[-1])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "sift1b", run, "100000", "2000", "1"])
+    outs = _run_cached_pair(exe, data, run)
 
     def parse(out):
         rec = [float(v) for v in re.findall(r"R@(?:1|10|100) = ([0-9.]+)", out)[-3:]]
@@ -126,7 +156,8 @@ def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
     rc, ic, dc = parse(outs["off"][0])
     rd, idd, dd = parse(outs["on"][0])
     summ = re.search(r"\[vlq-interpose\] device searches=(\d+) queries=(\d+) ncode=(\d+)", outs["on"][1])
-    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 1000 and int(summ.group(3)) > 0
+    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 2000 and int(summ.group(3)) > 0
+    _faster_on_the_device(outs)
     # 8-byte codes on 128 dimensions = 16-dimensional sub-vectors: there the reference computes its tables through
     # BLAS (ProductQuantizer.cpp:445-461,470-492; vendor-defined rounding), so the two runs agree to
     # rounding -- the north star's 1e-4 relative -- not digit for digit; the neighbours are the same up to near-ties
@@ -134,7 +165,8 @@ def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
     for a, b in zip(dc, dd):
         assert len(a) == len(b) == 10
         assert max(abs(float(x) - float(y)) / max(1e-9, abs(float(x))) for x, y in zip(a, b)) <= 1e-4
-    assert all(len(set(a) & set(b)) >= 9 for a, b in zip(ic, idd))
+    # (a sparse index may return fewer than 10 neighbours: the rest of a row is the reference's padding, id -1)
+    assert all(len(set(a) & set(b)) >= len(set(a)) - 1 for a, b in zip(ic, idd))
     assert max(abs(a - b) for a, b in zip(rc, rd)) <= 0.004
 
 
@@ -143,23 +175,18 @@ def test_sift1b_imi_pq_unchanged_on_the_device(tmp_path):
 def test_deep1b_drivers_unchanged_on_the_device(tmp_path, driver):
     """tests/deep1b_imi_pq.cpp and tests/deep1b16_imi_pq.cpp as shipped (BASELINE configs[3] / [4] name them: 96 dimensions,
     inverted multi-index 2 x 14 bits = 2^28 lists, 8- / 16-byte codes, nprobe 2048, k 128), compiled in place: CPU-only run,
-    then the device run of the SAME binary on the cached populated index the first run wrote; 8-byte codes are served by
-    scanm_kernel<8, ..., IMI>, 16-byte codes by scan16's table type 2.  Heavy like the sift1b driver (2^28 lists: 4.3 GB
-    index files): opt-in with VLQ_RUN_DEEP1B_DRIVERS=1; the run of record is profiles/r04_reference_drivers.txt."""
-    if os.environ.get("VLQ_RUN_DEEP1B_DRIVERS") != "1":
-        pytest.skip("opt-in: VLQ_RUN_DEEP1B_DRIVERS=1")
+    then the device run of the SAME binary, both on the driver's cached populated index; 8-byte codes are served by
+    scanm_kernel<8, ..., IMI>, 16-byte codes by scan16's table type 2.  Like the sift1b driver: 2^28 lists (4.3 GB index
+    files), 100 000 database vectors, 2000 queries, about a minute each (VLQ_SKIP_HEAVY_DRIVERS=1 leaves them out)."""
+    if os.environ.get("VLQ_SKIP_HEAVY_DRIVERS") == "1":
+        pytest.skip("VLQ_SKIP_HEAVY_DRIVERS=1")
     exe = os.path.join(RD, driver)
     if not (os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "oracle/_ref/libfaiss_ref.so"))):
         pytest.skip("tests/cpp/ref_drivers was not prebuilt (needs the reference tree at build time)")
     data, run = str(tmp_path / "data"), str(tmp_path / "run")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "deep1b", run, "500000", "1000"])
-    outs = {}
-    for mode in ("off", "on"):
-        p = subprocess.run([exe], env=_env({"VLQ_DATA_ROOT": data, "VLQ_INTERPOSE": mode}), capture_output=True, text=True,
-                           timeout=1100, cwd=run)
-        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-        outs[mode] = (p.stdout, p.stderr)
-        print(driver, mode, "\n".join(p.stdout.splitlines()[-6:]), p.stderr.splitlines()[-1])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_driver_data.py"), data, "deep1b", run, "100000", "2000",
+                           "8" if driver == "deep1b_imi_pq" else "16"])
+    outs = _run_cached_pair(exe, data, run)
 
     def parse(out):
         rec = [float(v) for v in re.findall(r"R@(?:1|10|100) = ([0-9.]+)", out)[-3:]]
@@ -169,11 +196,13 @@ def test_deep1b_drivers_unchanged_on_the_device(tmp_path, driver):
     rc, ic, dc = parse(outs["off"][0])
     rd, idd, dd = parse(outs["on"][0])
     summ = re.search(r"\[vlq-interpose\] device searches=(\d+) queries=(\d+) ncode=(\d+) .*cpu_fallbacks=(\d+)", outs["on"][1])
-    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 1000 and int(summ.group(3)) > 0 and int(summ.group(4)) == 0
+    assert summ and int(summ.group(1)) >= 1 and int(summ.group(2)) == 2000 and int(summ.group(3)) > 0 and int(summ.group(4)) == 0
+    _faster_on_the_device(outs)
     # sub-vectors of 12 / 6 dimensions: the reference's PQ tables take its SSE path (no BLAS), the coarse stage runs in the
     # reference's own code in both runs -- distances to the north star's 1e-4, the same neighbours up to near-ties
     assert len(rc) == 3 and len(dc) == 10 and len(dd) == 10
     for a, b in zip(dc, dd):
         assert max(abs(float(x) - float(y)) / max(1e-9, abs(float(x))) for x, y in zip(a, b)) <= 1e-4
-    assert all(len(set(a) & set(b)) >= 9 for a, b in zip(ic, idd))
+    # (a sparse index may return fewer than 10 neighbours: the rest of a row is the reference's padding, id -1)
+    assert all(len(set(a) & set(b)) >= len(set(a)) - 1 for a, b in zip(ic, idd))
     assert max(abs(a - b) for a, b in zip(rc, rd)) <= 0.004

@@ -6,6 +6,8 @@ truth by brute force.  The drivers' hard-coded /home/data prefix is redirected t
 (VLQ_DATA_ROOT).      python tools/make_driver_data.py <root> [nt nb nq]
                       python tools/make_driver_data.py <root> sift1b <cwd> [nb nq]
                       python tools/make_driver_data.py <root> deep1b <cwd> [nb nq]   (tests/deep1b_imi_pq.cpp, deep1b16_imi_pq.cpp)
+                      ... [nb nq populated]: also the drivers' POPULATED cache (sift1b: 1; deep1b: 8 or 16 = the code size), so that
+                      a test needs no populating run
 The second form prepares tests/sift1b_imi_pq.cpp: byte-valued base.umem / query.umem / learn.umem ("num dim" text
 header, data from byte 20, :100-150), gnd/idx_1000M.ivecs, and -- in <cwd>, where the driver looks for its cache
 (:225-243) -- sift1b_14_8_trained_index.faissindex in the reference's file format (index_io.cpp:226-317): the
@@ -62,10 +64,26 @@ def write_imi_ivfpq_index(path, d, imi_nbits, imi_centroids, M, pq_centroids, li
                 z.tofile(f)
             np.zeros(nlist & ((1 << 20) - 1), np.uint64).tofile(f)
             return
+        if isinstance(offsets, tuple):      # sparse: (sorted list ids of the non-empty lists, their lengths, starts in payload)
+            lid, ln, st = offsets
+            z = np.zeros(1 << 20, np.uint64)
+            prev = 0
+
+            def zeros(cnt):
+                while cnt > 0:
+                    c = min(cnt, z.size)
+                    z[:c].tofile(f)
+                    cnt -= c
+            for i in range(lid.size):
+                zeros(int(lid[i]) - prev)
+                vec(f, payload[int(st[i]) * width:(int(st[i]) + int(ln[i])) * width])
+                prev = int(lid[i]) + 1
+            zeros(nlist - prev)
+            return
         for i in range(nlist):
             vec(f, payload[offsets[i] * width:offsets[i + 1] * width])
 
-    ntotal = 0 if lists is None else int(lists[2][-1])
+    ntotal = 0 if lists is None else (int(lists[2][1].sum()) if isinstance(lists[2], tuple) else int(lists[2][-1]))
     with open(path, "wb") as f:
         f.write(b"IvPQ")
         hdr(f, d, ntotal)
@@ -81,6 +99,33 @@ def write_imi_ivfpq_index(path, d, imi_nbits, imi_centroids, M, pq_centroids, li
         list_vectors(f, M, None if lists is None else np.asarray(lists[0], np.uint8).reshape(-1), None if lists is None else lists[2])
 
 
+def populated_lists(xf, imi, pq, nbits, M):
+    """what the driver's add loop leaves in the lists (IndexIVFPQ::add_core_o, IndexIVFPQ.cpp:192-272): list = the nearest
+    sub-centroid of each half (i0 | i1 << nbits), code = the nearest PQ centroid of the residual per sub-quantizer, ids 0 .. n-1
+    in list order -- computed here so that the test starts from the driver's CACHED populated index (both runs equally cold)
+    instead of spending a CPU-only run on building it.  Returns (codes, ids, (list ids, lengths, starts))."""
+    n, d = xf.shape
+    hd, ds = d // 2, d // M
+    key = np.zeros(n, np.int64)
+    res = np.empty_like(xf)
+    for h in range(2):
+        sl = slice(h * hd, (h + 1) * hd)
+        a = np.empty(n, np.int64)
+        cn = (imi[h] ** 2).sum(1)
+        for i in range(0, n, 8192):
+            a[i:i + 8192] = (cn[None, :] - 2.0 * xf[i:i + 8192, sl] @ imi[h].T).argmin(1)
+        key |= a << (nbits * h)
+        res[:, sl] = xf[:, sl] - imi[h][a]
+    codes = np.empty((n, M), np.uint8)
+    for m in range(M):
+        sl = slice(m * ds, (m + 1) * ds)
+        codes[:, m] = (((pq[m] ** 2).sum(1))[None, :] - 2.0 * res[:, sl] @ pq[m].T).argmin(1)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    lid, st, ln = np.unique(ks, return_index=True, return_counts=True)
+    return codes[order], order.astype(np.int64), (lid, ln, st)
+
+
 def umem_write(path, x_u8):
     n, d = x_u8.shape
     with open(path, "wb") as f:
@@ -88,7 +133,7 @@ def umem_write(path, x_u8):
         np.ascontiguousarray(x_u8, np.uint8).tofile(f)
 
 
-def sift1b(root, cwd, nb=500000, nq=1000):
+def sift1b(root, cwd, nb=500000, nq=1000, populated=0):
     d, nc, sigma, rank, spread, kgt = 128, 2000, 0.005, 12, 0.4, 100
     centres = np.random.default_rng(1).random((nc, d)).astype(np.float32)
     sub = (np.random.default_rng(2).standard_normal((rank, d)) / np.sqrt(rank)).astype(np.float32)
@@ -126,8 +171,14 @@ def sift1b(root, cwd, nb=500000, nq=1000):
         a = (((imi[h] ** 2).sum(1))[None, :] - 2.0 * tr[:20000, sl] @ imi[h].T).argmin(1)
         res[:, sl] = tr[:20000, sl] - imi[h][a]
     pq = np.stack([res[r.permutation(20000)[:256], m * 16:(m + 1) * 16] for m in range(M)]).astype(np.float32)
-    write_imi_ivfpq_index(os.path.join(cwd, "sift1b_14_8_trained_index.faissindex"), d, nbits, imi, M, pq)
-    print("wrote %s/sift1b (base %d, query %d, ground truth %d) and %s/sift1b_14_8_trained_index.faissindex" % (root, nb, nq, kgt, cwd))
+    if populated:
+        # the driver loads the trained cache only to replace it by the populated one (:238-262): a 2 x 1-bit stand-in
+        write_imi_ivfpq_index(os.path.join(cwd, "sift1b_14_8_trained_index.faissindex"), d, 1, imi[:, :2], M, pq)
+        write_imi_ivfpq_index(os.path.join(cwd, "sift1b_14_8_populated_index.faissindex"), d, nbits, imi, M, pq,
+                              lists=populated_lists(xb.astype(np.float32), imi, pq, nbits, M))
+    else:
+        write_imi_ivfpq_index(os.path.join(cwd, "sift1b_14_8_trained_index.faissindex"), d, nbits, imi, M, pq)
+    print("wrote %s/sift1b (base %d, query %d, ground truth %d) and %s/sift1b_14_8_{trained,populated}_index.faissindex" % (root, nb, nq, kgt, cwd))
 
 
 def mem_write(path, x, dtype):
@@ -138,7 +189,7 @@ def mem_write(path, x, dtype):
         np.ascontiguousarray(x, dtype).tofile(f)
 
 
-def deep1b(root, cwd, nb=500000, nq=1000):
+def deep1b(root, cwd, nb=500000, nq=1000, populated=0):
     """tests/deep1b_imi_pq.cpp and tests/deep1b16_imi_pq.cpp (BASELINE configs[3] / [4] name them): float rows of 96
     dimensions in deep1B/{learn,base,query}.umem, ground truth in deep1B/truth.imem, and in <cwd> the trained-index caches
     both drivers look for (:246-256): deep1b_14_8_ / deep1b_14_16_trained_index.faissindex (multi-index 2 x 14 bits over
@@ -180,6 +231,13 @@ def deep1b(root, cwd, nb=500000, nq=1000):
     for M in (8, 16):
         ds = d // M
         pq = np.stack([res[r.permutation(20000)[:256], m * ds:(m + 1) * ds] for m in range(M)]).astype(np.float32)
+        if populated and populated != M:
+            continue               # (populated = 8 / 16: only that driver's files)
+        if populated:
+            write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_trained_index.faissindex" % M), d, 1, imi[:, :2], M, pq)
+            write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_populated_index.faissindex" % M), d, nbits, imi, M, pq,
+                                  lists=populated_lists(xb, imi, pq, nbits, M))
+            continue
         write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_trained_index.faissindex" % M), d, nbits, imi, M, pq)
     print("wrote %s/deep1B (base %d, query %d, ground truth %d) and %s/deep1b_14_{8,16}_trained_index.faissindex" % (root, nb, nq, kgt, cwd))
 
@@ -187,9 +245,9 @@ def deep1b(root, cwd, nb=500000, nq=1000):
 def main():
     root = sys.argv[1]
     if len(sys.argv) > 2 and sys.argv[2] == "sift1b":
-        return sift1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:6]))
+        return sift1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:7]))
     if len(sys.argv) > 2 and sys.argv[2] == "deep1b":
-        return deep1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:6]))
+        return deep1b(root, sys.argv[3], *(int(v) for v in sys.argv[4:7]))
     nt, nb, nq = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (40000, 200000, 1000)
     # low intrinsic dimension (what makes real descriptors rankable by short codes, bench.py's second data set):
     # most of a point's offset from its centre lies in one fixed 12-dimensional subspace

@@ -813,7 +813,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_own_recs, &h->ws_own_seg, &h->ws_own_items, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent,
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent, &h->ws_Dr, &h->ws_Ir,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi,
                       // the float16 screen of the coarse stage: built for every index at set_coarse_centroids
                       &h->screen.half, &h->screen.mu, &h->screen.norm_c, &h->imi_screen[0].half, &h->imi_screen[0].mu,
@@ -1174,7 +1174,9 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
                                  const float* coarse_dis, int nprobe, int k, float* D, int64_t* I,
                                  int store_pairs) {
     TRY(check_ready(h, true));
-    TRY(check_search_args(h, n, x, nprobe, k, D, I));
+    // more probes than one scan takes: the CPU class has no limit (tests/sift1b_imi_pq.cpp asks for 2048) -- see below
+    TRY(check_search_args(h, n, x, std::min(nprobe, VLQ_MAX_NPROBE), k, D, I));
+    if (nprobe > 64 * VLQ_MAX_NPROBE) return fail(VLQ_ERR_INVALID, "nprobe=%d beyond %d", nprobe, 64 * VLQ_MAX_NPROBE);
     if (n > 0 && (!keys || !coarse_dis)) return fail(VLQ_ERR_INVALID, "null keys/coarse_dis");
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
@@ -1186,8 +1188,30 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
     bool copyD, copyI;
     TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
     TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
-    TRY(scan_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k,
-                 (float*)Dd, (int64_t*)Id, store_pairs));
+    if (nprobe <= VLQ_MAX_NPROBE) {
+        TRY(scan_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k,
+                     (float*)Dd, (int64_t*)Id, store_pairs));
+    } else {
+        // The probe list is cut into runs of <= 1024 in coarse order (strided device copies of the staged arrays), every run is
+        // scanned, and the rows are joined by (distance, run, place in the run's row) -- the (distance, scan position) order
+        // of one long scan (merge_topk_kernel: ties go to the lower part, then the lower rank).
+        const int nruns = (nprobe + VLQ_MAX_NPROBE - 1) / VLQ_MAX_NPROBE;
+        TRY(h->ws_keys.reserve((size_t)n * VLQ_MAX_NPROBE * 8));
+        TRY(h->ws_cdis.reserve((size_t)n * VLQ_MAX_NPROBE * 4));
+        TRY(h->ws_Dr.reserve((size_t)nruns * n * k * 4));
+        TRY(h->ws_Ir.reserve((size_t)nruns * n * k * 8));
+        for (int r = 0; r < nruns; r++) {
+            const int p0 = r * VLQ_MAX_NPROBE, pn = std::min(VLQ_MAX_NPROBE, nprobe - p0);
+            HIP_TRY(hipMemcpy2DAsync(h->ws_keys.p, (size_t)pn * 8, (const int64_t*)kd + p0, (size_t)nprobe * 8, (size_t)pn * 8, (size_t)n,
+                                     hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpy2DAsync(h->ws_cdis.p, (size_t)pn * 4, (const float*)cd + p0, (size_t)nprobe * 4, (size_t)pn * 4, (size_t)n,
+                                     hipMemcpyDeviceToDevice, h->stream));
+            TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), pn, k,
+                         h->ws_Dr.as<float>() + (size_t)r * n * k, h->ws_Ir.as<int64_t>() + (size_t)r * n * k, store_pairs));
+        }
+        vlq::launch_merge_topk(h->ws_Dr.as<float>(), h->ws_Ir.as<int64_t>(), n, k, nruns, (float*)Dd, (int64_t*)Id, h->stream);
+        HIP_TRY(hipGetLastError());
+    }
     TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
     // host outputs: the call has synchronised, so an invalid key is reported here and now; device
     // outputs: the call stays asynchronous and the flag surfaces at the next vlq_ivfpq_stats()
