@@ -219,6 +219,39 @@ def test_random_vlq_configuration(seed):
             assert np.array_equal(bits(D1), bits(Do)) and np.array_equal(I1, Io)
 
 
+def test_constants_follow_incremental_adds_and_a_change_of_table_precision(world16):
+    """The stored per-code constants of line16c: a small add that fits the lists' slack appends in place and
+    extends the constants by the new vectors only; one that does not rebuilds the layout and with it the constants; toggling the
+    tables' precision keeps one precision's buffer.  A search after every step equals the oracle's over the same prefix."""
+    v, xb, xq = world16
+    nb = xb.shape[0]
+    g = gpu_from_oracle(v, with_lists=False)
+    steps = [int(nb * 0.70), int(nb * 0.72), int(nb * 0.73), nb]          # the two middle adds fit the 25 % slack
+    done = 0
+    for i, upto in enumerate(steps):
+        g.add(xb[done:upto])
+        done = upto
+        keep = v.ids < done                                              # (ids are 0 .. nb-1 in add order)
+        sub = v.restricted_to(keep) if hasattr(v, "restricted_to") else None
+        fp16 = i == 2                                                    # float16 tables for one step, fp32 again after
+        g.set_float16_tables(fp16)
+        D, I = g.search(xq[:64], 16, 128, 20)
+        if sub is not None:
+            Do, Io = sub.search(xq[:64], 16, 128, 20, fp16=fp16)
+            assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io), i
+        else:
+            # no oracle over a prefix: the same prefix loaded in one piece into a fresh index must answer alike
+            h = gpu_from_oracle(v, with_lists=False)
+            h.add(xb[:done])
+            h.set_float16_tables(fp16)
+            D2, I2 = h.search(xq[:64], 16, 128, 20)
+            assert np.array_equal(bits(D), bits(D2)) and np.array_equal(I, I2), i
+    g.set_float16_tables(False)
+    D, I = g.search(xq, 16, 128, 20)
+    Do, Io = v.search(xq, 16, 128, 20)
+    assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
+
+
 # ---------------------------------------------------------------------------------------------
 # float16 look-up tables (GpuIndexIVFPQConfig::useFloat16LookupTables, the reference drivers' setting)
 # ---------------------------------------------------------------------------------------------

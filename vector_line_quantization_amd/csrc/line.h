@@ -85,7 +85,8 @@ void launch_line16r_scan(const LineScanArgs& a, int dsub, hipStream_t s);
 // every code of every line, with the scan kernels' operations; term2h != nullptr: the float16 tables' form
 void launch_line_consts(const uint8_t* codes, const uint8_t* lambdas, const int64_t* line_off, const int64_t* line_len,
                         const int32_t* edge_info, const float* term2, const uint16_t* term2h, const float* lambda_info,
-                        int nedge, int M, int ksub, int64_t nlines, float* out, hipStream_t s);
+                        int nedge, int M, int ksub, int64_t nlines, float* out, hipStream_t s,
+                        const int* newcnt = nullptr);
 // 16-byte codes with the stored constants: one table per anchor centroid, no far-end rows; same results as
 // launch_line_scan, bit for bit
 bool line16c_supports(const LineScanArgs& a);

@@ -36,15 +36,19 @@ __global__ __launch_bounds__(256) void line_consts_kernel(const uint8_t* __restr
                                                           const int64_t* __restrict__ line_off, const int64_t* __restrict__ line_len,
                                                           const int32_t* __restrict__ edge_info, const float* __restrict__ term2,
                                                           const uint16_t* __restrict__ term2h, const float* __restrict__ lambda_info,
-                                                          int nedge, int M, int ksub, int64_t nlines, float* __restrict__ out) {
+                                                          int nedge, int M, int ksub, int64_t nlines, float* __restrict__ out,
+                                                          const int* __restrict__ newcnt) {
     const int64_t line = blockIdx.x;
     if (line >= nlines) return;
     const int64_t off = line_off[line];
     const int64_t len = line_len ? line_len[line] : line_off[line + 1] - off;
     if (len <= 0) return;
+    // newcnt (after an append in place): only the newcnt[line] vectors the line has just received, at its end
+    const int64_t first = newcnt ? len - (int64_t)newcnt[line] : 0;
+    if (first >= len) return;
     const size_t E = (size_t)M * ksub;
     const size_t rc = (size_t)(line / nedge) * E, rs = (size_t)edge_info[line] * E;
-    for (int64_t j = threadIdx.x; j < len; j += 256) {
+    for (int64_t j = first + threadIdx.x; j < len; j += 256) {
         const uint8_t* cj = codes + (off + j) * M;
         const float l = lambda_info[lambdas[off + j]];
         float tmp = 0.f;
@@ -65,15 +69,15 @@ __global__ __launch_bounds__(256) void line_consts_kernel(const uint8_t* __restr
 
 void launch_line_consts(const uint8_t* codes, const uint8_t* lambdas, const int64_t* line_off, const int64_t* line_len,
                         const int32_t* edge_info, const float* term2, const uint16_t* term2h, const float* lambda_info,
-                        int nedge, int M, int ksub, int64_t nlines, float* out, hipStream_t s) {
+                        int nedge, int M, int ksub, int64_t nlines, float* out, hipStream_t s, const int* newcnt) {
     if (nlines <= 0) return;
     // (the grid's x dimension holds 2^31 - 1 workgroups; the host checks nlist * nedge < 2^31)
     if (term2h)
         hipLaunchKernelGGL(line_consts_kernel<true>, dim3((unsigned)nlines), dim3(256), 0, s, codes, lambdas, line_off, line_len,
-                           edge_info, term2, term2h, lambda_info, nedge, M, ksub, nlines, out);
+                           edge_info, term2, term2h, lambda_info, nedge, M, ksub, nlines, out, newcnt);
     else
         hipLaunchKernelGGL(line_consts_kernel<false>, dim3((unsigned)nlines), dim3(256), 0, s, codes, lambdas, line_off, line_len,
-                           edge_info, term2, term2h, lambda_info, nedge, M, ksub, nlines, out);
+                           edge_info, term2, term2h, lambda_info, nedge, M, ksub, nlines, out, newcnt);
 }
 
 // ---------------------------------------------------------------------------
@@ -427,13 +431,13 @@ static void launch_line16c_t(const LineScanArgs& a, const L16cLayout& lay, size_
 // So a batch is split only while it cannot fill the chip: 250 queries (a 2000-query batch sharded over 8 GPUs)
 // 0.488 -> 0.355 ms with 3 parts.
 int line16c_parts(int64_t nq, int k, int max_parts) {
-    int cus = 256;
-    {
-        int dev = 0;
+    static const int cus = [] {        // (once per process: the query is not cheap, and this runs per search page)
+        int dev = 0, n = 256;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-            cus = pr.multiProcessorCount;
-    }
+            n = pr.multiProcessorCount;
+        return n;
+    }();
     const int64_t slots = (int64_t)cus * (k <= 256 ? 3 : 2);
     int p = 1;
     while (p < max_parts && nq * p * 10 < slots * 9) p++;

@@ -87,17 +87,29 @@ int encode_dev(vlq_line_t h, int64_t n, const float* xd) {
     return VLQ_OK;
 }
 
-// la * sum(term 4) of every stored code, in the precision of the tables the next scan uses
-int ensure_consts(vlq_line_t h, bool fp16) {
+// la * sum(term 4) of every stored code, in the precision of the tables the next scan uses.  Returns VLQ_OK with *have =
+// false when the 4 bytes per stored code cannot be had (the caller then scans with the stored term-2 rows, row mode 1, which
+// needs no extra memory: same results).  Only ONE precision is kept: the other one's buffer goes back when the tables' precision
+// is toggled (4 GB each at 10^9 codes).  newcnt != nullptr: only the vectors an in-place append has just added (lists.h).
+int ensure_consts(vlq_line_t h, bool fp16, bool* have, const int* newcnt = nullptr) {
     vlq_ivfpq_t b = h->base;
     bool& valid = fp16 ? h->pconsth_valid : h->pconst_valid;
-    if (valid) return VLQ_OK;
+    *have = true;
+    if (valid && !newcnt) return VLQ_OK;
     DevBuf& buf = fp16 ? h->pconsth : h->pconst;
-    TRY(buf.reserve(h->codes.cap / (size_t)b->M * 4 + 16));      // one float per code slot of the current layout
+    DevBuf& other = fp16 ? h->pconst : h->pconsth;
+    if (other.p) { other.release(); (fp16 ? h->pconst_valid : h->pconsth_valid) = false; }
+    if (newcnt && buf.cap < h->codes.cap / (size_t)b->M * 4 + 16) newcnt = nullptr;      // (a grown buffer starts empty: everything)
+    if (buf.reserve(h->codes.cap / (size_t)b->M * 4 + 16) != VLQ_OK) {      // one float per code slot of the current layout
+        (void)hipGetLastError();
+        valid = false;
+        *have = false;
+        return VLQ_OK;
+    }
     vlq::launch_line_consts(h->codes.as<uint8_t>(), h->lambdas.as<uint8_t>(), h->line_off.as<int64_t>(),
                             h->line_len.as<int64_t>(), h->edge_info.as<int32_t>(), b->term2.as<float>(),
                             fp16 ? h->term2h.as<uint16_t>() : nullptr, h->lambda_info.as<float>(), h->nedge, b->M, b->ksub,
-                            h->nlines, buf.as<float>(), b->stream);
+                            h->nlines, buf.as<float>(), b->stream, newcnt);
     HIP_TRY(hipGetLastError());
     valid = true;
     return VLQ_OK;
@@ -369,12 +381,23 @@ int vlq_line_add(vlq_line_t h, int64_t n, const float* x, const int64_t* xids) {
     const void* idd = nullptr;
     if (xids) TRY(stage_in(b, xids, (size_t)n * 8, h->ws_keys, &idd));
     vlq::ListStore ls = line_store(h);
-    drop_consts(h);              // (the append may move every list; the constants are rebuilt before the next search)
     int64_t placed = 0;
-    TRY(vlq::lists_append(ls, h->ws_append, n, nullptr, h->ws_line.as<int32_t>(), h->ws_codes.as<uint8_t>(),
-                          h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream, &placed));
+    bool relaid = false;
+    const int rc = vlq::lists_append(ls, h->ws_append, n, nullptr, h->ws_line.as<int32_t>(), h->ws_codes.as<uint8_t>(),
+                                     h->ws_lamb.as<uint8_t>(), (const int64_t*)idd, h->ntotal_added, b->stream, &placed, &relaid);
+    if (rc != VLQ_OK) { drop_consts(h); return rc; }
     h->ntotal += placed;         // vectors without a line are dropped
     h->ntotal_added += n;
+    // the stored codes' constants (line16c.hip): an append in place adds the new vectors' only -- O(batch), not O(database), per
+    // add; a rebuilt layout (amortised: 25 % slack) moves every list, the constants are then rebuilt before the next search
+    if (relaid || !b->term2_valid) drop_consts(h);
+    else {
+        for (int fp16 = 0; fp16 < 2; fp16++) {
+            if (!(fp16 ? h->pconsth_valid : h->pconst_valid)) continue;
+            bool have = false;
+            TRY(ensure_consts(h, fp16 != 0, &have, h->ws_append.cnt.as<int>()));
+        }
+    }
     return VLQ_OK;
 }
 
@@ -480,9 +503,9 @@ int vlq_line_search(vlq_line_t h, int64_t n, const float* x, int nprobe, int w1,
                                         metaj, h->ws_sel_cnt.as<int32_t>() + j0);
         }
         // the stored codes' share of the distance (line16c.hip), once per database state
-        const bool use_consts = !rebuilt_rows && (h->row_mode == 0 || h->row_mode == 3) && with_meta && b->M == 16 &&
-                                b->ksub == 256 && w1 <= 1024 && h->ntotal > 0;
-        if (use_consts) TRY(ensure_consts(h, fp16));
+        bool use_consts = !rebuilt_rows && (h->row_mode == 0 || h->row_mode == 3) && with_meta && b->M == 16 &&
+                          b->ksub == 256 && w1 <= 1024 && h->ntotal > 0;
+        if (use_consts) TRY(ensure_consts(h, fp16, &use_consts));        // (no memory for them: the stored-row kernel below)
         // 3. per-query <q_m, cent_mj> (term 3 / -2, IVFPQ.cu:1409-1432)
         vlq::launch_pq_tables(xi, ni, b->d, b->pq.as<float>(), b->M, b->ksub, b->dsub, nullptr, 0,
                               b->ws_qtab.as<float>(), b->stream);

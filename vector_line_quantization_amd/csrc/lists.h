@@ -33,7 +33,9 @@ inline void release(AppendWorkspace& w) { w.cnt.release(); w.cstart.release(); w
 // assign32 != nullptr: int32 list ids (VLQ lines) instead of assign64.
 int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* assign64,
                  const int32_t* assign32, const uint8_t* new_codes, const uint8_t* new_lambdas,
-                 const int64_t* xids, int64_t id_base, hipStream_t s, int64_t* placed = nullptr);
+                 const int64_t* xids, int64_t id_base, hipStream_t s, int64_t* placed = nullptr, bool* relaid = nullptr);
+// (*relaid: the append rebuilt the layout -- every list may have moved; otherwise the batch sits behind the old ends of the
+// lists and ws.cnt[i] (int) is the number of vectors list i received)
 
 int lists_sync_host(ListStore& ls, hipStream_t s);
 int lists_relayout(ListStore& ls, std::vector<int64_t>& new_off, hipStream_t s);

@@ -217,8 +217,9 @@ int lists_reclaim(ListStore& ls, uint64_t* bytes, hipStream_t s) {
 
 int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* assign64,
                  const int32_t* assign32, const uint8_t* new_codes, const uint8_t* new_lambdas,
-                 const int64_t* xids, int64_t id_base, hipStream_t s, int64_t* placed) {
+                 const int64_t* xids, int64_t id_base, hipStream_t s, int64_t* placed, bool* relaid) {
     if (placed) *placed = 0;
+    if (relaid) *relaid = false;
     if (n <= 0) return VLQ_OK;
     if (n > 0x7FFFFFFFll) return fail(VLQ_ERR_INVALID, "add(): at most 2^31-1 vectors per call");
     if (ls.nlist >= 0xFFFFFFFFll) return fail(VLQ_ERR_UNSUPPORTED, "more than 2^32-2 lists");
@@ -283,6 +284,7 @@ int lists_append(ListStore& ls, AppendWorkspace& ws, int64_t n, const int64_t* a
         caps.release();
         if (e != hipSuccess) { noff.release(); return fail(VLQ_ERR_HIP, "list growth failed: %s", hipGetErrorString(e)); }
         TRY(relayout_dev(ls, noff, cap, s));
+        if (relaid) *relaid = true;
     }
 
     // 3. place the batch, then publish the new lengths
