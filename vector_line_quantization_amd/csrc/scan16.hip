@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                 if (B == 0) { float (&v)[8] = h4; VLQ_G8HI_NW(0, cb.z, cb.w); } else { float (&v)[8] = h4; VLQ_G8HI_NW(16384, cb.z, cb.w); }
                 // chunk A's admission test while chunk B's reads are in flight; the (rare) insertion itself
                 // waits until nothing is in flight: no control flow between an LDS read and its wait
-                const bool hit_a = __builtin_amdgcn_ballot_w64(da < sel.thr) != 0;
+                const bool hit_a = __builtin_amdgcn_ballot_w64(da <= sel.thr) != 0;
                 VLQ_WAIT8(8, h3);
                 float db = dis0;
 #pragma unroll
@@ -358,14 +358,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                 VLQ_WAIT8(0, h4);
 #pragma unroll
                 for (int m = 0; m < 8; m++) db = __fadd_rn(db, h4[m]);
-                if (hit_a) sel.offer(da, pos0 + ja, true);
-                sel.offer(db, pos0 + jb, jb < len);
+                if (hit_a) sel.offer_keyed(da, pos0 + ja, true);
+                sel.offer_keyed(db, pos0 + jb, jb < len);
             }
             for (; !AHEAD && j0 < len; j0 += NT) {           // (the pair loop's odd last chunk)
                 const uint32_t j = j0 + lane;
                 const uint4 cn = cp[min(j + NT, len - 1)];
                 const float dis = adc16_halves<B>(cc, dis0, two);
-                sel.offer(dis, pos0 + j, j < len);
+                sel.offer_keyed(dis, pos0 + j, j < len);
                 cc = cn;
             }
             if (AHEAD) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                             if (j0e < len) {
                                 VLQ_PH_TRIP();
                                 const float dis = adc16_halves<B>(cur[e], dis0, two);
-                                sel.offer(dis, pos0 + j0e + lane, j0e + lane < len);
+                                sel.offer_keyed(dis, pos0 + j0e + lane, j0e + lane < len);
                             }
                         }
                     }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                     asm volatile("" : "+s"(g));        // (keeps the two halves of the trip from being threaded into two copies of the loads)
                     if (g && kAblGather) {
                         const uint4 cur = cr[C];
-                        if (kAblSelect) asm volatile("" :: "v"(cur.x)); else sel.offer(dis0 + __uint_as_float(cur.x & 0x3fffffffu), pos0 + jc + lane, jc + lane < len);
+                        if (kAblSelect) asm volatile("" :: "v"(cur.x)); else sel.offer_keyed(dis0 + __uint_as_float(cur.x & 0x3fffffffu), pos0 + jc + lane, jc + lane < len);
                     }
                     if (g && !kAblGather) {
                         float dis = dis0;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                         for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hi[m]);
                         VLQ_PH_G1();
                         if (kAblSelect) asm volatile("" :: "v"(dis));
-                        else sel.offer(dis, pos0 + jc + lane, jc + lane < len);
+                        else sel.offer_keyed(dis, pos0 + jc + lane, jc + lane < len);
                     }
                 };
                 trip(std::integral_constant<int, 0>{});
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void scan16_short_kernel(ScanArgs a, int queue
             float dis = dis0;
 #pragma unroll
             for (int m = 0; m < 16; m++) dis = __fadd_rn(dis, e[m]);
-            sel.offer(dis, pos0 + j, j < len);
+            sel.offer_keyed(dis, pos0 + j, j < len);
             cc = cn;
         }
     }

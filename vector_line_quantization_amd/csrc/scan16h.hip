@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void scan16h_kernel(ScanArgs a, int lut_region
 #pragma unroll
                     for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, h2f(vh[m]));
                 }
-                sel.offer(dis, pos0 + j, j < len);
+                sel.offer_keyed(dis, pos0 + j, j < len);
                 cc = cn;
             }
         };

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void scan16o_kernel(ScanArgs a, int lut_region
             for (uint32_t j0 = (uint32_t)wave * 64; j0 < len; j0 += NT) {
                 const uint32_t j = j0 + lane;
                 const float dis = adc16_halves<B>(cc, dis0, two);
-                sel.offer(dis, pos0 + j, j < len);
+                sel.offer_keyed(dis, pos0 + j, j < len);
                 if (j0 + NT < len) cc = cp[min(j + NT, len - 1)];   // (wave-uniform) most lists end within the trip
             }
         };

@@ -57,6 +57,33 @@ __device__ __forceinline__ float adc_m(const uint32_t (&w)[M / 4], float dis, ui
     return dis;
 }
 
+// The same sum in two pieces: front() ends when the last half block's reads are issued -- every word of the code has been
+// turned into addresses, its registers may be reloaded (the scan requests the next list's chunk there) -- back() adds the last
+// two half blocks.  Same order of the additions, same counted waits.
+template <int M, int O> struct AdcSplit {
+    static constexpr int NH = M / 8;
+    float hb[NH][8];
+    template <int S> __device__ __forceinline__ void add(float& dis) {
+        wait_hb<(S == NH - 1) ? 0 : 8>(hb[S]);
+#pragma unroll
+        for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hb[S][m]);
+        asm volatile("" : "+v"(dis));
+    }
+    __device__ __forceinline__ void front(const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
+        issue_hb<O>(hb[0], w[0], w[1], two);
+        if constexpr (NH > 1) issue_hb<O + 8192>(hb[1], w[2], w[3], two);
+        if constexpr (NH == 4) {
+            add<0>(dis); issue_hb<O + 2 * 8192>(hb[2], w[4], w[5], two);
+            add<1>(dis); issue_hb<O + 3 * 8192>(hb[3], w[6], w[7], two);
+        }
+        static_assert(NH == 1 || NH == 2 || NH == 4, "8-, 16- and 32-byte codes");
+    }
+    __device__ __forceinline__ void back(float& dis) {
+        if constexpr (NH == 1) add<0>(dis);
+        else { add<NH - 2>(dis); add<NH - 1>(dis); }
+    }
+};
+
 template <int M> struct CodeWords { uint32_t w[M / 4]; };
 template <int M>
 __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ base, int64_t row) {
@@ -223,18 +250,32 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
     uint32_t n_len = 0, n_pos0 = 0;
     float n_dis0 = 0.f;
     int64_t n_off = 0;
-    auto prefetch = [&](int i) __attribute__((always_inline)) {
+    // (scan16.hip, round 5) the codes of a list are requested a whole probe ahead, chunk c of the next list into the registers
+    // the trip that consumed chunk c of this one has just freed; every load of a probe is issued unconditionally and in one
+    // place, so the compiler's vmcnt counts are exact (with the next chunk requested under a condition inside the list loop it
+    // waited for vmcnt(0) in every trip: for the NEXT probe's row and codes, requested just before the barrier)
+    constexpr bool AHEAD = DSUB == 0 && KPL <= 2 && M == 32;
+    constexpr int NPRE = M == 8 ? 3 : 2;           // chunks of a list requested a probe ahead (32-byte codes: registers)
+    constexpr int NEX = M == 8 ? 4 : 1;            // chunks of a longer list in flight at a time
+    CodeWords<M> cr[NPRE];
+#pragma unroll
+    for (int c = 0; c < NPRE; c++)
+#pragma unroll
+        for (int i = 0; i < M / 4; i++) cr[c].w[i] = 0;
+    int64_t n_key = 0;
+    auto prefetch_meta = [&](int i) __attribute__((always_inline)) {
         if (i >= nlive) return;
         const int p = ord[i];
-        const int64_t key = pm.pkey[p];
+        n_key = (int64_t)__builtin_amdgcn_readfirstlane(pm.pkey[p]);
         n_len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
         n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
         n_pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
-        {
-            const int64_t o = pm.poff[p];
-            n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
-                              __builtin_amdgcn_readfirstlane((uint32_t)o));
-        }
+        const int64_t o = pm.poff[p];
+        n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
+                          __builtin_amdgcn_readfirstlane((uint32_t)o));
+    };
+    auto load_rows = [&]() __attribute__((always_inline)) {
+        const int64_t key = n_key;
         if constexpr (DSUB > 0) {
             // (table mode 0: no term2 row; the coarse centroid is requested by fetch_coarse, two probes ahead)
         } else if (IMI) {
@@ -251,11 +292,25 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
         }
-        c0 = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t, n_len - 1));
+    };
+    auto load_chunk = [&](auto cc_) __attribute__((always_inline)) {
+        constexpr int C = decltype(cc_)::value;
+        cr[C] = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t + C * NT, n_len - 1));
+    };
+    auto prefetch = [&](int i) __attribute__((always_inline)) {
+        if (i >= nlive) return;
+        prefetch_meta(i);
+        load_rows();
+        if (AHEAD) {
+            load_chunk(std::integral_constant<int, 0>{});
+            load_chunk(std::integral_constant<int, 1>{});
+            if constexpr (NPRE == 3) load_chunk(std::integral_constant<int, 2>{});
+        } else c0 = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t, n_len - 1));
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
     const unsigned long long t_walk = wall_clock64();
     prefetch(i_begin);
+    if (AHEAD) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): nothing pending on the way into the loop (scan16.hip)
     // table mode 0: component t of the coarse centroid of the i-th walked probe, requested two probes ahead; the residual
     // x - centroid (compute_residual, IndexIVFPQ.cpp:636) of the next probe is written to LDS while the current table is built
     constexpr int DV = M * (DSUB > 0 ? DSUB : 1);
@@ -273,11 +328,13 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
     }
     int buf = 0;
     uint64_t nscan = 0;
-    for (int i = i_begin; i < i_end; i++) {
+    // one probe; BUF >= 0: the table buffer is known at compile time (the pair loop below), -1: taken from buf
+    auto probe = [&](int i, auto fixed_) __attribute__((always_inline)) {
+        constexpr int FIXED = decltype(fixed_)::value;
         const uint32_t len = n_len, pos0 = n_pos0;
         const float dis0 = DSUB > 0 ? 0.f : n_dis0;  // mode 0: dis0 = 0 (IndexIVFPQ.cpp:638)
         const int64_t off = n_off;
-        float* L = lut + buf * E;
+        float* L = lut + (FIXED >= 0 ? FIXED : buf) * E;
         if (NBUF == 1) __syncthreads();              // single table buffer: everyone is done scanning with it
         __builtin_amdgcn_s_setprio(2);               // table build + the next list's first loads first (scan16.hip)
         if constexpr (DSUB > 0) {
@@ -308,7 +365,7 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
             }
         }
         CodeWords<M> cc = c0;
-        prefetch(i + 1);
+        if (AHEAD) prefetch_meta(i + 1); else prefetch(i + 1);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (sel.dirty) {
@@ -319,6 +376,90 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
         auto scan_list = [&](auto bufc) {
             constexpr int B = decltype(bufc)::value;
             uint32_t j0 = (uint32_t)wave * 64;
+            if constexpr (AHEAD) {
+                const uint32_t w64 = j0;
+                // a list longer than NPRE chunks: its further chunks first (the order inside a list is free: walk_order.cuh), NEX
+                // at a time, reloaded in place (clamped: behind the list's end a cache hit nobody uses).  Requested here and not
+                // before the barrier: registers defined under one condition and used under another made the compiler copy them
+                // behind a vmcnt(0) on EVERY path.
+                const uint32_t w64x = w64 + NPRE * NT;
+                if (w64x < len) {
+                    CodeWords<M> ex[NEX];
+#pragma unroll
+                    for (int e = 0; e < NEX; e++) ex[e] = load_code<M>(a.codes, off + (int64_t)min(w64x + e * NT + lane, len - 1));
+                    for (uint32_t jx = w64x; jx < len; jx += NEX * NT) {
+#pragma unroll
+                        for (int e = 0; e < NEX; e++) {
+                            const uint32_t j0e = jx + e * NT;
+                            uint32_t g = j0e < len ? 1u : 0u;
+                            AdcSplit<M, B * E * 4> ad;
+                            float dis = dis0;
+                            if (g) ad.front(ex[e].w, dis, two);
+                            ex[e] = load_code<M>(a.codes, off + (int64_t)min(j0e + NEX * NT + lane, len - 1));
+                            g = __builtin_amdgcn_readfirstlane(g);
+                            asm volatile("" : "+s"(g));
+                            if (g) {
+                                ad.back(dis);
+                                sel.offer_keyed(dis, pos0 + j0e + lane, j0e + lane < len);
+                            }
+                        }
+                    }
+                }
+                auto trip = [&](auto cc_) {
+                    constexpr int C = decltype(cc_)::value;
+                    const uint32_t jc = w64 + C * NT;
+                    uint32_t g = jc < len ? 1u : 0u;      // (wave-uniform)
+                    AdcSplit<M, B * E * 4> ad;
+                    float dis = dis0;
+                    if (g) ad.front(cr[C].w, dis, two);
+                    load_chunk(cc_);
+                    if (C == 0) load_rows();          // behind the chunk: vmcnt retires in order
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    asm volatile("" : "+s"(g));        // (keeps the two halves of the trip from being threaded into two copies of the loads)
+                    if (g) {
+                        ad.back(dis);
+                        sel.offer_keyed(dis, pos0 + jc + lane, jc + lane < len);
+                    }
+                };
+                if constexpr (M == 8) {
+                    // 8-byte codes are one half block: chunks 0 and 1 as one trip, the adds of the first under the reads of the
+                    // second (what the half-block pipeline does inside a longer code)
+                    uint32_t ga = w64 < len ? 1u : 0u, gb = w64 + NT < len ? 1u : 0u;
+                    float ha[8], hb2[8];
+                    if (ga) issue_hb<B * E * 4>(ha, cr[0].w[0], cr[0].w[1], two);
+                    if (gb) issue_hb<B * E * 4>(hb2, cr[1].w[0], cr[1].w[1], two);
+                    load_chunk(std::integral_constant<int, 0>{});
+                    load_rows();
+                    load_chunk(std::integral_constant<int, 1>{});
+                    ga = __builtin_amdgcn_readfirstlane(ga);
+                    gb = __builtin_amdgcn_readfirstlane(gb);
+                    asm volatile("" : "+s"(ga), "+s"(gb));
+                    if (gb) {
+                        wait_hb<8>(ha);
+                        float da = dis0;
+#pragma unroll
+                        for (int m = 0; m < 8; m++) da = __fadd_rn(da, ha[m]);
+                        asm volatile("" : "+v"(da));
+                        wait_hb<0>(hb2);
+                        float db = dis0;
+#pragma unroll
+                        for (int m = 0; m < 8; m++) db = __fadd_rn(db, hb2[m]);
+                        sel.offer_keyed(da, pos0 + w64 + lane, true);
+                        sel.offer_keyed(db, pos0 + w64 + NT + lane, w64 + NT + lane < len);
+                    } else if (ga) {
+                        wait_hb<0>(ha);
+                        float da = dis0;
+#pragma unroll
+                        for (int m = 0; m < 8; m++) da = __fadd_rn(da, ha[m]);
+                        sel.offer_keyed(da, pos0 + w64 + lane, w64 + lane < len);
+                    }
+                    trip(std::integral_constant<int, 2>{});
+                } else {
+                    trip(std::integral_constant<int, 0>{});
+                    trip(std::integral_constant<int, 1>{});
+                }
+                return;
+            }
             if constexpr (M == 8) {
                 // 8-byte codes are one half block: two chunks per trip, the adds of the first under the reads of the second
                 // (what the half-block pipeline does inside a longer code)
@@ -339,8 +480,8 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
                     float db = dis0;
 #pragma unroll
                     for (int m = 0; m < 8; m++) db = __fadd_rn(db, hb2[m]);
-                    sel.offer(da, pos0 + ja, true);
-                    sel.offer(db, pos0 + jb, jb < len);
+                    sel.offer_keyed(da, pos0 + ja, true);
+                    sel.offer_keyed(db, pos0 + jb, jb < len);
                     cc = cn;
                 }
             }
@@ -349,14 +490,28 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
                 CodeWords<M> cn = cc;
                 if (j0 + NT < len) cn = load_code<M>(a.codes, off + (int64_t)min(j + NT, len - 1));   // (wave-uniform)
                 const float dis = adc_m<M, B * E * 4>(cc.w, dis0, two);
-                sel.offer(dis, pos0 + j, j < len);
+                sel.offer_keyed(dis, pos0 + j, j < len);
                 cc = cn;
             }
         };
-        if (NBUF == 1 || buf == 0) scan_list(std::integral_constant<int, 0>{});
+        if constexpr (FIXED >= 0) scan_list(std::integral_constant<int, FIXED>{});
+        else if (NBUF == 1 || buf == 0) scan_list(std::integral_constant<int, 0>{});
         else scan_list(std::integral_constant<int, NBUF == 2 ? 1 : 0>{});
         nscan += len;
-        if (NBUF == 2) buf ^= 1;
+        if (NBUF == 2 && FIXED < 0) buf ^= 1;
+    };
+    if constexpr (AHEAD && NBUF == 2) {
+        // two probes per trip of the loop, one per table buffer: with one copy of the list loop per buffer behind a run-time
+        // choice, the registers the next list's codes are loaded into had two load sites merging at the loop's end -- copies
+        // behind a vmcnt(0), i.e. a wait for everything just requested
+        int i = i_begin;
+        for (; i + 1 < i_end; i += 2) {
+            probe(i, std::integral_constant<int, 0>{});
+            probe(i + 1, std::integral_constant<int, 1>{});
+        }
+        if (i < i_end) probe(i, std::integral_constant<int, 0>{});
+    } else {
+        for (int i = i_begin; i < i_end; i++) probe(i, std::integral_constant<int, -1>{});
     }
     if (t == 0) walk_state_finish(a, t_walk, i_end - i_begin, walk_mean);
     merge_and_emit<KPL, NW>(sel, smraw, pm.cum, a, a.nsplit > 1 ? (int64_t)part * a.nq + q : q, wave, lane,

@@ -206,7 +206,7 @@ __device__ __forceinline__ void wave_sort_multi(u64 (&p)[R], int lane) {
 // the register allocation of the caller's hot loop does not see the ~40 temporaries of the sort /
 // merge network; whatever has to be saved around the call is saved in the rare branch only.
 template <int KPL>
-struct BestList { u64 v[KPL]; float kth; };
+struct BestList { u64 v[KPL]; float kth; uint32_t kth_pos; };
 
 // (the parked keys travel by value too: read through the callee's generic pointer they were FLAT
 // loads whose wait drained the caller's outstanding global prefetches at every flush)
@@ -232,6 +232,7 @@ __device__ __forceinline__ BestList<KPL> flush_body(BestList<KPL> b, Pending<QR>
     const u64 kth = bcast_u64(row, kl);
     // a missing k-th (kMaxKey) keeps the threshold at FLT_MAX
     b.kth = (kth == kMaxKey) ? 3.402823466e+38f : ordered_to_f32((uint32_t)(kth >> 32));
+    b.kth_pos = (kth == kMaxKey) ? 0u : (uint32_t)kth;
     return b;
 }
 template <int KPL, int QR>
@@ -245,6 +246,7 @@ struct WaveSelect {
     u64 best[KPL];
     float thr;        // admission threshold: min(thr_own, bound shared by the workgroup)
     float thr_own;    // distance of this wave's k-th best, or FLT_MAX
+    uint32_t pos_own; // ... and its position (0 with FLT_MAX: nothing precedes it)
     int npend;        // entries parked in `queue` (wave-uniform)
     int k;
     int lane;
@@ -265,6 +267,7 @@ struct WaveSelect {
 #pragma unroll
         for (int r = 0; r < KPL; r++) best[r] = kMaxKey;
         thr = thr_own = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
+        pos_own = 0;
         thr_sh = __builtin_inff();
         dirty = false;
         npend = 0;
@@ -288,6 +291,7 @@ struct WaveSelect {
         npend = 0;
         // (wave-uniform: keep it in a scalar register)
         thr_own = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b.kth)));
+        pos_own = __builtin_amdgcn_readfirstlane(b.kth_pos);
         thr = fminf(thr_own, thr_sh);
         dirty = true;
     }
@@ -305,15 +309,19 @@ struct WaveSelect {
     // exact.  ORDERED = false (positions arrive out of order): equal distances are queued too and
     // the full (distance, position) key decides at the merge; FLT_MAX itself is never admitted
     // (the reference's heap starts at FLT_MAX and admits only `dis < top`, Heap.h:76-78).
-    template <bool ORDERED = true>
+    template <bool ORDERED = true, bool KEYED = false>
     __device__ __forceinline__ void offer(float dis, uint32_t pos, bool valid) {
-        bool pred = valid && (ORDERED ? dis < thr : (dis <= thr && dis < 3.402823466e+38f));
+        auto admit = [&](bool first) __attribute__((always_inline)) {
+            if (KEYED) return dis < thr || (dis == thr_own && pos < pos_own);
+            return ORDERED ? dis < thr : (dis <= thr && (!first || dis < 3.402823466e+38f));
+        };
+        bool pred = valid && admit(true);
         u64 mask = __ballot(pred);
         if (mask == 0) return;
         int c = __popcll(mask);
         if (npend + c > 64 * QR) {
             flush();
-            pred = pred && (ORDERED ? dis < thr : dis <= thr);
+            pred = pred && admit(false);
             mask = __ballot(pred);
             if (mask == 0) return;
             c = __popcll(mask);
@@ -324,6 +332,13 @@ struct WaveSelect {
         }
         npend += c;
     }
+    // The list scans: a wave's candidates arrive in ANY order of their positions (the walking order of the lists, a long
+    // list's further chunks before its first ones), so a candidate AT the wave's k-th distance is admitted when its position
+    // precedes the k-th key's -- the full (distance, position) order, the one the reference's heap leaves behind
+    // (`dis < top` in scan order: among equal distances the first scanned stays, Heap.h:76-78).  Until round 5 the scans
+    // used the ordered rule: a tie at the k-th distance scanned earlier by the reference but visited later here was dropped
+    // (tests/test_gpu_ties.py).  FLT_MAX is never admitted: thr_own = FLT_MAX comes with pos_own = 0.
+    __device__ __forceinline__ void offer_keyed(float dis, uint32_t pos, bool valid) { offer<false, true>(dis, pos, valid); }
 
     // same, for ready-made keys (block-level merge of per-wave results)
     __device__ __forceinline__ void offer_key(u64 key, bool valid) {
