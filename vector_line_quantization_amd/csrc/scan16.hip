@@ -296,11 +296,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
             for (int i2 = 0; i2 < NI; i2++) asm volatile("" :: "v"(t2r[i2].x), "v"(t2r[i2].y), "v"(t2r[i2].z), "v"(t2r[i2].w));
         } else build_lut16<NI>(L, t, t2r, m2t3);
         uint4 cc = cr[0], cd = cr[1];
-        // a list longer than NPRE chunks: its next four chunks requested now (the row registers are free once the table is
-        // stored), in flight across the barrier
+        // a list longer than NPRE chunks: its next two chunks requested now (the row registers are free once the table is
+        // stored), in flight across the barrier (four until the keyed admission arrived: at 128 VGPRs the two-wave shape
+        // then spilled a pair of table registers and reloaded it -- behind a vmcnt(0) -- in every table build)
         const uint32_t w64x = (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64 + NPRE * NT;
         const bool hasx = AHEAD && w64x < len;
-        constexpr int NEX = KPL == 1 ? 4 : 2;      // (two for the 128-key selections: their registers)
+        constexpr int NEX = 2;
         uint4 ex[NEX];
         if (hasx) {
 #pragma unroll
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((((KPL 
                 if (B == 0) { float (&v)[8] = h4; VLQ_G8HI_NW(0, cb.z, cb.w); } else { float (&v)[8] = h4; VLQ_G8HI_NW(16384, cb.z, cb.w); }
                 // chunk A's admission test while chunk B's reads are in flight; the (rare) insertion itself
                 // waits until nothing is in flight: no control flow between an LDS read and its wait
-                const bool hit_a = __builtin_amdgcn_ballot_w64(da <= sel.thr) != 0;
+                const bool hit_a = __builtin_amdgcn_ballot_w64(da <= sel.thr_le) != 0;
                 VLQ_WAIT8(8, h3);
                 float db = dis0;
 #pragma unroll

@@ -123,9 +123,10 @@ template <int M> struct ScanMShape {
 // keeps the DSUB components of its 4 * NI centroids in registers for the whole query (d floats: 128 VGPRs at d = 128), the
 // residual of the NEXT probe is formed one probe ahead in LDS; the generic kernel re-read the 128 KB codebook from L2 per
 // probe (3.25 ms per 10 000 queries on the bench index against 0.73 with the precomputed table).
-template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0>
-__global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_eu((M == 32 && DSUB == 0 && KPL == 1) ? 4 : 1))) void scanm_kernel(ScanArgs a, int lut_region) {
-    constexpr int NW = ScanMShape<M>::NW, NT = ScanMShape<M>::NT, E = ScanMShape<M>::E, NI = ScanMShape<M>::NI;
+// NWX: waves per workgroup when not the shape's (8-byte codes, large batches: 2 -- see launch_scanm_k)
+template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0, int NWX = 0>
+__global__ __launch_bounds__(64 * (NWX ? NWX : ScanMShape<M>::NW)) __attribute__((amdgpu_waves_per_eu((M == 32 && DSUB == 0 && KPL == 1) ? 4 : (M == 8 && DSUB == 0 && KPL == 1) ? (NWX == 2 ? 5 : 6) : 1))) void scanm_kernel(ScanArgs a, int lut_region) {
+    constexpr int NW = NWX ? NWX : ScanMShape<M>::NW, NT = 64 * NW, E = ScanMShape<M>::E, NI = E / 4 / NT;
     static_assert(DSUB == 0 || (NBUF == 2 && !IMI), "table mode 0: two table buffers, flat coarse quantizer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* lut = reinterpret_cast<float*>(smraw);                         // [NBUF][E] at LDS byte 0
@@ -243,39 +244,48 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
     WaveSelect<KPL, 1, (KPL >= 2)> sel;
     sel.init(a.k, queue + wave * 64, lane);
 
-    float4 t2r[NI];
     CodeWords<M> c0;
 #pragma unroll
     for (int i = 0; i < M / 4; i++) c0.w[i] = 0;
-    uint32_t n_len = 0, n_pos0 = 0;
-    float n_dis0 = 0.f;
-    int64_t n_off = 0;
     // (scan16.hip, round 5) the codes of a list are requested a whole probe ahead, chunk c of the next list into the registers
     // the trip that consumed chunk c of this one has just freed; every load of a probe is issued unconditionally and in one
     // place, so the compiler's vmcnt counts are exact (with the next chunk requested under a condition inside the list loop it
-    // waited for vmcnt(0) in every trip: for the NEXT probe's row and codes, requested just before the barrier)
+    // waited for vmcnt(0) in every trip: for the NEXT probe's row and codes, requested just before the barrier).
+    // 8-byte codes: TWO probes ahead (DEPTH 2, register sets alternating with the table buffers): three trips of 8 gathers
+    // are over long before a row requested one probe earlier has crossed the fabric.
+    #ifdef VLQ_SCANM8_OLD
     constexpr bool AHEAD = DSUB == 0 && KPL <= 2 && M == 32;
-    constexpr int NPRE = M == 8 ? 3 : 2;           // chunks of a list requested a probe ahead (32-byte codes: registers)
+#else
+    constexpr bool AHEAD = DSUB == 0 && KPL <= 2 && M <= 32;
+#endif
+    constexpr int DEPTH = (AHEAD && NBUF == 2) ? 2 : 1;
+    constexpr int NPRE = M == 8 ? 3 : 2;           // chunks of a list requested ahead (32-byte codes: registers)
     constexpr int NEX = M == 8 ? 4 : 1;            // chunks of a longer list in flight at a time
-    CodeWords<M> cr[NPRE];
+    struct ProbeRegs { uint32_t len = 0, pos0 = 0; float dis0 = 0.f; int64_t off = 0, key = 0; };   // (wave-uniform)
+    ProbeRegs nx[DEPTH];
+    float4 t2s[DEPTH][NI];
+    CodeWords<M> cr[DEPTH][NPRE];
 #pragma unroll
-    for (int c = 0; c < NPRE; c++)
+    for (int s = 0; s < DEPTH; s++)
 #pragma unroll
-        for (int i = 0; i < M / 4; i++) cr[c].w[i] = 0;
-    int64_t n_key = 0;
-    auto prefetch_meta = [&](int i) __attribute__((always_inline)) {
-        if (i >= nlive) return;
+        for (int c = 0; c < NPRE; c++)
+#pragma unroll
+            for (int i = 0; i < M / 4; i++) cr[s][c].w[i] = 0;
+    auto prefetch_meta = [&](int i, auto set_) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_)::value;
+        if (i >= nlive) return;      // (a part may look past its range, the last probes past the end: harmless repeated loads)
         const int p = ord[i];
-        n_key = (int64_t)__builtin_amdgcn_readfirstlane(pm.pkey[p]);
-        n_len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
-        n_dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
-        n_pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
+        nx[S].key = (int64_t)__builtin_amdgcn_readfirstlane(pm.pkey[p]);
+        nx[S].len = __builtin_amdgcn_readfirstlane(pm.plen[p]);
+        nx[S].dis0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pm.pd0[p])));
+        nx[S].pos0 = __builtin_amdgcn_readfirstlane(pm.cum[p]);
         const int64_t o = pm.poff[p];
-        n_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
-                          __builtin_amdgcn_readfirstlane((uint32_t)o));
+        nx[S].off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)o >> 32)) << 32) |
+                              __builtin_amdgcn_readfirstlane((uint32_t)o));
     };
-    auto load_rows = [&]() __attribute__((always_inline)) {
-        const int64_t key = n_key;
+    auto load_rows = [&](auto set_) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_)::value;
+        const int64_t key = nx[S].key;
         if constexpr (DSUB > 0) {
             // (table mode 0: no term2 row; the coarse centroid is requested by fetch_coarse, two probes ahead)
         } else if (IMI) {
@@ -285,31 +295,32 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) {
                 const int64_t ki = (NW * i2 + wave) < M / 2 ? ki0 : ki1;
-                t2r[i2] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i2 * NT + t];
+                t2s[S][i2] = reinterpret_cast<const float4*>(a.term2 + (size_t)ki * E)[i2 * NT + t];
             }
         } else {
             const float4* src = reinterpret_cast<const float4*>(a.term2 + (size_t)key * E);
 #pragma unroll
-            for (int i2 = 0; i2 < NI; i2++) t2r[i2] = src[i2 * NT + t];
+            for (int i2 = 0; i2 < NI; i2++) t2s[S][i2] = src[i2 * NT + t];
         }
     };
-    auto load_chunk = [&](auto cc_) __attribute__((always_inline)) {
-        constexpr int C = decltype(cc_)::value;
-        cr[C] = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t + C * NT, n_len - 1));
+    auto load_chunk = [&](auto set_, auto cc_) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_)::value, C = decltype(cc_)::value;
+        cr[S][C] = load_code<M>(a.codes, nx[S].off + (int64_t)min((uint32_t)t + C * NT, nx[S].len - 1));
     };
-    auto prefetch = [&](int i) __attribute__((always_inline)) {
+    auto prefetch = [&](int i, auto set_) __attribute__((always_inline)) {
         if (i >= nlive) return;
-        prefetch_meta(i);
-        load_rows();
+        prefetch_meta(i, set_);
+        load_rows(set_);
         if (AHEAD) {
-            load_chunk(std::integral_constant<int, 0>{});
-            load_chunk(std::integral_constant<int, 1>{});
-            if constexpr (NPRE == 3) load_chunk(std::integral_constant<int, 2>{});
-        } else c0 = load_code<M>(a.codes, n_off + (int64_t)min((uint32_t)t, n_len - 1));
+            load_chunk(set_, std::integral_constant<int, 0>{});
+            load_chunk(set_, std::integral_constant<int, 1>{});
+            if constexpr (NPRE == 3) load_chunk(set_, std::integral_constant<int, 2>{});
+        } else c0 = load_code<M>(a.codes, nx[0].off + (int64_t)min((uint32_t)t, nx[0].len - 1));
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
     const unsigned long long t_walk = wall_clock64();
-    prefetch(i_begin);
+    prefetch(i_begin, std::integral_constant<int, 0>{});
+    if constexpr (DEPTH == 2) prefetch(i_begin + 1, std::integral_constant<int, 1>{});
     if (AHEAD) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): nothing pending on the way into the loop (scan16.hip)
     // table mode 0: component t of the coarse centroid of the i-th walked probe, requested two probes ahead; the residual
     // x - centroid (compute_residual, IndexIVFPQ.cpp:636) of the next probe is written to LDS while the current table is built
@@ -331,9 +342,12 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
     // one probe; BUF >= 0: the table buffer is known at compile time (the pair loop below), -1: taken from buf
     auto probe = [&](int i, auto fixed_) __attribute__((always_inline)) {
         constexpr int FIXED = decltype(fixed_)::value;
-        const uint32_t len = n_len, pos0 = n_pos0;
-        const float dis0 = DSUB > 0 ? 0.f : n_dis0;  // mode 0: dis0 = 0 (IndexIVFPQ.cpp:638)
-        const int64_t off = n_off;
+        constexpr int S = DEPTH == 2 ? FIXED : 0;     // register set of this probe
+        static_assert(DEPTH == 1 || FIXED >= 0, "two probes ahead: the pair loop");
+        const std::integral_constant<int, S> set_{};
+        const uint32_t len = nx[S].len, pos0 = nx[S].pos0;
+        const float dis0 = DSUB > 0 ? 0.f : nx[S].dis0;  // mode 0: dis0 = 0 (IndexIVFPQ.cpp:638)
+        const int64_t off = nx[S].off;
         float* L = lut + (FIXED >= 0 ? FIXED : buf) * E;
         if (NBUF == 1) __syncthreads();              // single table buffer: everyone is done scanning with it
         __builtin_amdgcn_s_setprio(2);               // table build + the next list's first loads first (scan16.hip)
@@ -359,13 +373,13 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
 #pragma unroll
             for (int i2 = 0; i2 < NI; i2++) {
                 float4 sv;
-                sv.x = __fadd_rn(t2r[i2].x, m2t3[i2].x); sv.y = __fadd_rn(t2r[i2].y, m2t3[i2].y);
-                sv.z = __fadd_rn(t2r[i2].z, m2t3[i2].z); sv.w = __fadd_rn(t2r[i2].w, m2t3[i2].w);
+                sv.x = __fadd_rn(t2s[S][i2].x, m2t3[i2].x); sv.y = __fadd_rn(t2s[S][i2].y, m2t3[i2].y);
+                sv.z = __fadd_rn(t2s[S][i2].z, m2t3[i2].z); sv.w = __fadd_rn(t2s[S][i2].w, m2t3[i2].w);
                 reinterpret_cast<float4*>(L)[i2 * NT + t] = sv;
             }
         }
         CodeWords<M> cc = c0;
-        if (AHEAD) prefetch_meta(i + 1); else prefetch(i + 1);
+        if (AHEAD) prefetch_meta(i + DEPTH, set_); else prefetch(i + 1, set_);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (sel.dirty) {
@@ -387,23 +401,30 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
                     CodeWords<M> ex[NEX];
 #pragma unroll
                     for (int e = 0; e < NEX; e++) ex[e] = load_code<M>(a.codes, off + (int64_t)min(w64x + e * NT + lane, len - 1));
-                    for (uint32_t jx = w64x; jx < len; jx += NEX * NT) {
+                    uint32_t jx = w64x;
+                    for (; jx + NEX * NT < len; jx += NEX * NT) {        // rounds with a further round behind them: all NEX chunks real
 #pragma unroll
                         for (int e = 0; e < NEX; e++) {
                             const uint32_t j0e = jx + e * NT;
-                            uint32_t g = j0e < len ? 1u : 0u;
                             AdcSplit<M, B * E * 4> ad;
                             float dis = dis0;
-                            if (g) ad.front(ex[e].w, dis, two);
+                            ad.front(ex[e].w, dis, two);
                             ex[e] = load_code<M>(a.codes, off + (int64_t)min(j0e + NEX * NT + lane, len - 1));
-                            g = __builtin_amdgcn_readfirstlane(g);
-                            asm volatile("" : "+s"(g));
-                            if (g) {
-                                ad.back(dis);
-                                sel.offer_keyed(dis, pos0 + j0e + lane, j0e + lane < len);
-                            }
+                            ad.back(dis);
+                            sel.offer_keyed(dis, pos0 + j0e + lane, j0e + lane < len);
                         }
                     }
+#pragma unroll
+                    for (int e = 0; e < NEX; e++) {                      // the last round requests nothing
+                        const uint32_t j0e = jx + e * NT;
+                        if (j0e < len) {
+                            const float dis = adc_m<M, B * E * 4>(ex[e].w, dis0, two);
+                            sel.offer_keyed(dis, pos0 + j0e + lane, j0e + lane < len);
+                        }
+                    }
+                    // (nothing of this block is in flight behind it: what the compiler must assume pending where the two
+                    // paths meet decides the waits of EVERY probe)
+                    if (NEX > 1) __builtin_amdgcn_s_waitcnt(0x0F70);
                 }
                 auto trip = [&](auto cc_) {
                     constexpr int C = decltype(cc_)::value;
@@ -411,9 +432,9 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
                     uint32_t g = jc < len ? 1u : 0u;      // (wave-uniform)
                     AdcSplit<M, B * E * 4> ad;
                     float dis = dis0;
-                    if (g) ad.front(cr[C].w, dis, two);
-                    load_chunk(cc_);
-                    if (C == 0) load_rows();          // behind the chunk: vmcnt retires in order
+                    if (g) ad.front(cr[S][C].w, dis, two);
+                    load_chunk(set_, cc_);
+                    if (C == 0) load_rows(set_);      // behind the chunk: vmcnt retires in order
                     g = __builtin_amdgcn_readfirstlane(g);
                     asm volatile("" : "+s"(g));        // (keeps the two halves of the trip from being threaded into two copies of the loads)
                     if (g) {
@@ -421,42 +442,13 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
                         sel.offer_keyed(dis, pos0 + jc + lane, jc + lane < len);
                     }
                 };
-                if constexpr (M == 8) {
-                    // 8-byte codes are one half block: chunks 0 and 1 as one trip, the adds of the first under the reads of the
-                    // second (what the half-block pipeline does inside a longer code)
-                    uint32_t ga = w64 < len ? 1u : 0u, gb = w64 + NT < len ? 1u : 0u;
-                    float ha[8], hb2[8];
-                    if (ga) issue_hb<B * E * 4>(ha, cr[0].w[0], cr[0].w[1], two);
-                    if (gb) issue_hb<B * E * 4>(hb2, cr[1].w[0], cr[1].w[1], two);
-                    load_chunk(std::integral_constant<int, 0>{});
-                    load_rows();
-                    load_chunk(std::integral_constant<int, 1>{});
-                    ga = __builtin_amdgcn_readfirstlane(ga);
-                    gb = __builtin_amdgcn_readfirstlane(gb);
-                    asm volatile("" : "+s"(ga), "+s"(gb));
-                    if (gb) {
-                        wait_hb<8>(ha);
-                        float da = dis0;
-#pragma unroll
-                        for (int m = 0; m < 8; m++) da = __fadd_rn(da, ha[m]);
-                        asm volatile("" : "+v"(da));
-                        wait_hb<0>(hb2);
-                        float db = dis0;
-#pragma unroll
-                        for (int m = 0; m < 8; m++) db = __fadd_rn(db, hb2[m]);
-                        sel.offer_keyed(da, pos0 + w64 + lane, true);
-                        sel.offer_keyed(db, pos0 + w64 + NT + lane, w64 + NT + lane < len);
-                    } else if (ga) {
-                        wait_hb<0>(ha);
-                        float da = dis0;
-#pragma unroll
-                        for (int m = 0; m < 8; m++) da = __fadd_rn(da, ha[m]);
-                        sel.offer_keyed(da, pos0 + w64 + lane, w64 + lane < len);
-                    }
-                    trip(std::integral_constant<int, 2>{});
-                } else {
+                {
+                    // (8-byte codes: chunks 0 and 1 as ONE trip -- the adds of the first under the reads of the second, as the
+                    // loop without the look-ahead has it -- measured 0.50 / 0.54 ms on the two bench data sets against 0.36 /
+                    // 0.42: its 16 more live registers do not fit the 80 of six waves per SIMD)
                     trip(std::integral_constant<int, 0>{});
                     trip(std::integral_constant<int, 1>{});
+                    if constexpr (NPRE == 3) trip(std::integral_constant<int, 2>{});
                 }
                 return;
             }
@@ -520,16 +512,16 @@ __global__ __launch_bounds__(ScanMShape<M>::NT) __attribute__((amdgpu_waves_per_
     if (badkey) *a.bad_key = 1;
 }
 
-template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0>
+template <int M, int KPL, int NBUF, bool IMI, int DSUB = 0, int NWX = 0>
 static void launch_scanm_i(const ScanArgs& a, hipStream_t s) {
-    constexpr int NW = ScanMShape<M>::NW, E = ScanMShape<M>::E;
+    constexpr int NW = NWX ? NWX : ScanMShape<M>::NW, E = ScanMShape<M>::E;
     size_t lutb = (size_t)NBUF * E * 4;
     const size_t merge = (size_t)NW * a.k * 8;
     if (lutb < merge) lutb = merge;
     const size_t tail = (size_t)NW * 64 * 8 + (size_t)a.nprobe * 24 + 8 + 8 + (size_t)a.nprobe * 2 + 8 + 64 + (size_t)2 * M * DSUB * 4 + 16;
     const size_t smem = lutb + tail;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(scanm_kernel<M, KPL, NBUF, IMI, DSUB>), smem);
-    hipLaunchKernelGGL((scanm_kernel<M, KPL, NBUF, IMI, DSUB>), dim3((unsigned)(8 * a.xcd_chunk)), dim3(64 * NW), smem, s, a, (int)lutb);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(scanm_kernel<M, KPL, NBUF, IMI, DSUB, NWX>), smem);
+    hipLaunchKernelGGL((scanm_kernel<M, KPL, NBUF, IMI, DSUB, NWX>), dim3((unsigned)(8 * a.xcd_chunk)), dim3(64 * NW), smem, s, a, (int)lutb);
 }
 // table mode 0 (DSUB = d / M components per sub-quantizer)
 template <int M, int DSUB>
@@ -545,7 +537,14 @@ static void launch_scanm_k(const ScanArgs& a, hipStream_t s) {
         if (a.imi_nbits > 0) launch_scanm_i<M, K, NBUF, true>(a, s);    \
         else launch_scanm_i<M, K, NBUF, false>(a, s);                   \
     } while (0)
-    if (a.k <= 64) VLQ_SM(1);
+    // 8-byte codes, k <= 64, 3000 queries and more: two waves per workgroup.  The kernel is bound by the instructions it issues
+    // (profiles/r05_code_sizes.txt: 4100 VALU + 2400 SALU per wave at four waves, 3/4 of them per-probe work every wave
+    // repeats -- metadata, addresses, table build, threshold -- for 1.3 trips of 8 gathers); two waves halve that share
+    static const int nw8_env = [] { const char* e = getenv("VLQ_SCANM8_WAVES"); return e ? atoi(e) : 0; }();
+    if (M == 8 && a.k <= 64 && (nw8_env ? nw8_env == 2 : a.nq * a.nsplit >= 3000)) {
+        if (a.imi_nbits > 0) launch_scanm_i<M, 1, NBUF, true, 0, M == 8 ? 2 : 0>(a, s);
+        else launch_scanm_i<M, 1, NBUF, false, 0, M == 8 ? 2 : 0>(a, s);
+    } else if (a.k <= 64) VLQ_SM(1);
     else if (a.k <= 128) VLQ_SM(2);
     else if (a.k <= 256) VLQ_SM(4);
     else VLQ_SM(16);

@@ -247,6 +247,7 @@ struct WaveSelect {
     float thr;        // admission threshold: min(thr_own, bound shared by the workgroup)
     float thr_own;    // distance of this wave's k-th best, or FLT_MAX
     uint32_t pos_own; // ... and its position (0 with FLT_MAX: nothing precedes it)
+    float thr_le;     // keyed admission (offer_keyed): nothing above min(thr_own, shared minimum) can be admitted
     int npend;        // entries parked in `queue` (wave-uniform)
     int k;
     int lane;
@@ -261,13 +262,15 @@ struct WaveSelect {
     // of the word -- the kernel, with plain LDS instructions -- publishes `thr_own` when `dirty` and
     // hands the current minimum to refresh_with().
     float thr_sh;     // nextup of the last shared minimum seen (+inf: none)
+    float t_sh;       // the last shared minimum itself
     bool dirty;       // thr_own changed since the caller last published it
 
     __device__ __forceinline__ void init(int k_, u64* queue_, int lane_) {
 #pragma unroll
         for (int r = 0; r < KPL; r++) best[r] = kMaxKey;
-        thr = thr_own = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
+        thr = thr_own = thr_le = 3.402823466e+38f;   // FLT_MAX: Heap.h:76-78 neutral element
         pos_own = 0;
+        t_sh = __builtin_inff();
         thr_sh = __builtin_inff();
         dirty = false;
         npend = 0;
@@ -293,6 +296,7 @@ struct WaveSelect {
         thr_own = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b.kth)));
         pos_own = __builtin_amdgcn_readfirstlane(b.kth_pos);
         thr = fminf(thr_own, thr_sh);
+        thr_le = fminf(thr_own, t_sh);
         dirty = true;
     }
 
@@ -300,7 +304,9 @@ struct WaveSelect {
     __device__ __forceinline__ void refresh_with(uint32_t shared_ordered) {
         const float t = ordered_to_f32(shared_ordered) + 0.0f;      // -0 -> +0: nextup(-0) must be > +0
         thr_sh = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ordered_to_f32(f32_to_ordered(t) + 1u))));
+        t_sh = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t)));
         thr = fminf(thr_own, thr_sh);
+        thr_le = fminf(thr_own, t_sh);
     }
 
     // one candidate per lane (`valid` lanes only); wave-uniform control flow.
@@ -315,6 +321,9 @@ struct WaveSelect {
             if (KEYED) return dis < thr || (dis == thr_own && pos < pos_own);
             return ORDERED ? dis < thr : (dis <= thr && (!first || dis < 3.402823466e+38f));
         };
+        // (keyed: one compare in the scan loop -- whatever is admitted lies at or under min(own k-th, shared minimum); the
+        // position is looked at only when a lane passes)
+        if (KEYED && __ballot(valid && dis <= thr_le) == 0) return;
         bool pred = valid && admit(true);
         u64 mask = __ballot(pred);
         if (mask == 0) return;
