@@ -398,48 +398,83 @@ __device__ __forceinline__ float exact_distance(const float* qrow, const float* 
     return __fsub_rn(__fadd_rn(qnv, cnv), __fmul_rn(2.f, ip));
 }
 
-// Everything the screen needs of a batch of rows x [n][d], one pass: a workgroup stages 64 rows in LDS with coalesced
-// loads (rows padded to d + 1 floats), then
+// Everything the screen needs of a batch of rows x [n][d], one pass: a workgroup stages 32 rows in LDS with coalesced
+// loads, then
 //   * all threads write half(scale * (x - mu)) in the MFMA's operand order: rows in blocks of 32, components in steps of
 //     16; block (row / 32, ks) is 1 KB = lane (r = row % 32, h = (k % 16) / 8) x 8 halves, so a wave's operand load of one
 //     block is one contiguous KB.  Rows n .. n_pad - 1 (n_pad = n rounded up to 128) and components d .. 16 ks_n - 1 are zero;
-//   * one thread per row walks its row -- the reference's additions are sequential -- for the squared norm in
-//     fvec_norm_L2sqr's order (norm_sse_order: what the matrix path uses; the exact distances need it), the squared norm of
-//     the centred row (the approximate matrix and delta need it; any order) and the half-range flag of the centred, scaled
-//     row (flags optional).
-__global__ __launch_bounds__(256) void screen_prep_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d,
+//   * four threads per row, one per lane accumulator of fvec_norm_L2sqr (utils.cpp:538-556: s_l += x[4i+l]^2 in increasing i,
+//     then (s0 + s1) + (s2 + s3) -- the matrix path's norm_sse_order, bit for bit: the exact distances need it), which also
+//     sum their quarter of the centred row's squared norm (the approximate matrix and delta need it; any order) and of the
+//     half-range flag of the centred, scaled row (flags optional).  (One thread per row until round 5: 64 of the workgroup's
+//     256 threads walked 128 components twice while the others waited -- 13.2 us per 10 000 rows.)
+// d % 4 == 0 (coarse_screen_shape_ok); rows padded to d + 4 floats: a quad's four lanes read consecutive words, eight rows
+// cover the 32 banks.
+constexpr int kPrepRows = 32;
+__global__ __launch_bounds__(128) void screen_prep_kernel(const float* __restrict__ x, const float* __restrict__ mu, int64_t n, int d,
                                                           int ks_n, float scale, _Float16* __restrict__ out, float* __restrict__ norms,
                                                           float* __restrict__ norms_c, unsigned char* __restrict__ flags) {
-    extern __shared__ float rows[];                            // [64][d + 1]
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    const int nr = (int)max((int64_t)0, min((int64_t)64, n - row0));
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [kPrepRows][d + 4]
+    const int ld = d + 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kPrepRows;
+    const int nr = (int)max((int64_t)0, min((int64_t)kPrepRows, n - row0));
     const int t = threadIdx.x;
-    for (int e = t; e < nr * d; e += 256) rows[(e / d) * (d + 1) + e % d] = x[row0 * d + e];
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4* src = reinterpret_cast<const float4*>(x + row0 * d);
+        const int d4 = d >> 2;
+        for (int e = t; e < nr * d4; e += 128) *reinterpret_cast<float4*>(rows + (e / d4) * ld + 4 * (e % d4)) = src[e];
+    } else {
+        for (int e = t; e < nr * d; e += 128) rows[(e / d) * ld + e % d] = x[row0 * d + e];
+    }
     __syncthreads();
     const int gpr = 2 * ks_n;                                  // 8-component groups per row
-    for (int e = t; e < 64 * gpr; e += 256) {
-        const int r = e / gpr, grp = e % gpr, ks = grp >> 1, h = grp & 1;
+    // lanes along the rows: the 32 rows' pieces of one (ks, h) are 512 contiguous bytes of the operand block (lanes along the
+    // groups wrote 16 bytes every KB: 64 lines per store instruction)
+    for (int e = t; e < kPrepRows * gpr; e += 128) {
+        const int r = e & (kPrepRows - 1), grp = e / kPrepRows, ks = grp >> 1, h = grp & 1;
+        float xv[8];
+        if (8 * grp + 8 <= d) {
+            const float4 a = *reinterpret_cast<const float4*>(rows + r * ld + 8 * grp), b = *reinterpret_cast<const float4*>(rows + r * ld + 8 * grp + 4);
+            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) xv[i] = 8 * grp + i < d ? rows[r * ld + 8 * grp + i] : 0.f;
+        }
         h16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int k = 8 * grp + i;
-            v[i] = (_Float16)((r < nr && k < d) ? __fmul_rn(scale, __fsub_rn(rows[r * (d + 1) + k], mu[k])) : 0.f);
+            v[i] = (_Float16)((r < nr && k < d) ? __fmul_rn(scale, __fsub_rn(xv[i], mu[k])) : 0.f);
         }
         const int64_t row = row0 + r;
         *reinterpret_cast<h16x8*>(out + (((row >> 5) * ks_n + ks) * 64 + h * 32 + (row & 31)) * 8) = v;
     }
-    if (t >= nr) return;
-    const float* xr = rows + t * (d + 1);
+    const int r = t >> 2, l = t & 3;
+    const float* xr = rows + min(r, max(nr - 1, 0)) * ld;      // (threads of missing rows walk the last one: shuffles stay uniform)
+    float sl = 0.f, nc = 0.f;
     bool bad = false;
-    float nc = 0.f;
-    for (int c = 0; c < d; c++) {
-        const float w = __fsub_rn(xr[c], mu[c]);
-        nc = __fmaf_rn(w, w, nc);
-        bad = bad || !(fabsf(__fmul_rn(scale, w)) <= 65504.f);      // also true for NaN
+    if (nr > 0) {
+        for (int c = l; c < d; c += 4) {
+            const float v = xr[c];
+            sl = __fadd_rn(sl, __fmul_rn(v, v));
+            const float w = __fsub_rn(v, mu[c]);
+            nc = __fmaf_rn(w, w, nc);
+            bad = bad || !(fabsf(__fmul_rn(scale, w)) <= 65504.f);      // also true for NaN
+        }
+        sl = __fadd_rn(sl, 0.f);                               // (the reference's unconditional tail add)
     }
-    norms[row0 + t] = norm_sse_order([&](int c) { return xr[c]; }, d);
-    norms_c[row0 + t] = nc;
-    if (flags) flags[row0 + t] = bad ? 1 : 0;
+    // (s0 + s1) + (s2 + s3): the quad's pairs, then the two pair sums
+    const float pr = __fadd_rn(sl, __shfl_xor(sl, 1));
+    const float nrm = __fadd_rn(pr, __shfl_xor(pr, 2));
+    nc += __shfl_xor(nc, 1);
+    nc += __shfl_xor(nc, 2);
+    const int badq = (int)bad | __shfl_xor((int)bad, 1);
+    const int bada = badq | __shfl_xor(badq, 2);
+    if (l == 0 && r < nr) {
+        norms[row0 + r] = nrm;
+        norms_c[row0 + r] = nc;
+        if (flags) flags[row0 + r] = bada ? 1 : 0;
+    }
 }
 
 constexpr int kKeepCap = 512;                   // kept columns per row (typically nprobe + 20); more -> the row is done exactly
@@ -945,7 +980,7 @@ void launch_screen_prep(const float* x, const float* mu, int64_t n, int d, float
                         unsigned char* flags, hipStream_t s) {
     if (n <= 0) return;
     const int64_t n_pad = (n + 127) / 128 * 128;
-    hipLaunchKernelGGL(screen_prep_kernel, dim3((unsigned)(n_pad / 64)), dim3(256), (size_t)64 * (d + 1) * sizeof(float), s, x, mu, n, d,
+    hipLaunchKernelGGL(screen_prep_kernel, dim3((unsigned)(n_pad / kPrepRows)), dim3(128), (size_t)kPrepRows * (d + 4) * sizeof(float), s, x, mu, n, d,
                        (d + 15) / 16, scale, reinterpret_cast<_Float16*>(out_half), norms, norms_c, flags);
 }
 
