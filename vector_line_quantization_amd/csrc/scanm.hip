@@ -307,8 +307,11 @@ __global__ __launch_bounds__(64 * (NWX ? NWX : ScanMShape<M>::NW)) __attribute__
         constexpr int S = decltype(set_)::value, C = decltype(cc_)::value;
         cr[S][C] = load_code<M>(a.codes, nx[S].off + (int64_t)min((uint32_t)t + C * NT, nx[S].len - 1));
     };
-    auto prefetch = [&](int i, auto set_) __attribute__((always_inline)) {
-        if (i >= nlive) return;
+    // (guarded: the first request of a workgroup, which may have no live probe at all; inside the probe loop the loads are
+    // unconditional -- past the last probe they repeat its addresses -- a load under a condition made the compiler copy half a
+    // row behind a vmcnt(6) right after requesting it: 64-byte codes 3.82 -> 4.18 ms)
+    auto prefetch = [&](int i, auto set_, bool guarded) __attribute__((always_inline)) {
+        if (guarded && i >= nlive) return;
         prefetch_meta(i, set_);
         load_rows(set_);
         if (AHEAD) {
@@ -319,8 +322,8 @@ __global__ __launch_bounds__(64 * (NWX ? NWX : ScanMShape<M>::NW)) __attribute__
     };
     const int i_begin = (int)((int64_t)part * nlive / a.nsplit), i_end = (int)((int64_t)(part + 1) * nlive / a.nsplit);
     const unsigned long long t_walk = wall_clock64();
-    prefetch(i_begin, std::integral_constant<int, 0>{});
-    if constexpr (DEPTH == 2) prefetch(i_begin + 1, std::integral_constant<int, 1>{});
+    prefetch(i_begin, std::integral_constant<int, 0>{}, true);
+    if constexpr (DEPTH == 2) prefetch(i_begin + 1, std::integral_constant<int, 1>{}, true);
     if (AHEAD) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): nothing pending on the way into the loop (scan16.hip)
     // table mode 0: component t of the coarse centroid of the i-th walked probe, requested two probes ahead; the residual
     // x - centroid (compute_residual, IndexIVFPQ.cpp:636) of the next probe is written to LDS while the current table is built
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(64 * (NWX ? NWX : ScanMShape<M>::NW)) __attribute__
             }
         }
         CodeWords<M> cc = c0;
-        if (AHEAD) prefetch_meta(i + DEPTH, set_); else prefetch(i + 1, set_);
+        if (AHEAD) prefetch_meta(i + DEPTH, set_); else prefetch(i + 1, set_, false);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (sel.dirty) {

@@ -347,7 +347,11 @@ struct WaveSelect {
     // (`dis < top` in scan order: among equal distances the first scanned stays, Heap.h:76-78).  Until round 5 the scans
     // used the ordered rule: a tie at the k-th distance scanned earlier by the reference but visited later here was dropped
     // (tests/test_gpu_ties.py).  FLT_MAX is never admitted: thr_own = FLT_MAX comes with pos_own = 0.
+#ifdef VLQ_KEYED_OFF      // (timing A/B only: the ordered rule drops ties, tests/test_gpu_ties.py)
+    __device__ __forceinline__ void offer_keyed(float dis, uint32_t pos, bool valid) { offer<true, false>(dis, pos, valid); }
+#else
     __device__ __forceinline__ void offer_keyed(float dis, uint32_t pos, bool valid) { offer<false, true>(dis, pos, valid); }
+#endif
 
     // same, for ready-made keys (block-level merge of per-wave results)
     __device__ __forceinline__ void offer_key(u64 key, bool valid) {
