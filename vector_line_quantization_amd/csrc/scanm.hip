@@ -69,14 +69,17 @@ template <int M, int O> struct AdcSplit {
         for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hb[S][m]);
         asm volatile("" : "+v"(dis));
     }
+    template <int S> __device__ __forceinline__ void roll(const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
+        if constexpr (S + 2 < NH) {
+            add<S>(dis);
+            issue_hb<O + (S + 2) * 8192>(hb[S + 2], w[2 * (S + 2)], w[2 * (S + 2) + 1], two);
+            roll<S + 1>(w, dis, two);
+        }
+    }
     __device__ __forceinline__ void front(const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
         issue_hb<O>(hb[0], w[0], w[1], two);
         if constexpr (NH > 1) issue_hb<O + 8192>(hb[1], w[2], w[3], two);
-        if constexpr (NH == 4) {
-            add<0>(dis); issue_hb<O + 2 * 8192>(hb[2], w[4], w[5], two);
-            add<1>(dis); issue_hb<O + 3 * 8192>(hb[3], w[6], w[7], two);
-        }
-        static_assert(NH == 1 || NH == 2 || NH == 4, "8-, 16- and 32-byte codes");
+        roll<0>(w, dis, two);
     }
     __device__ __forceinline__ void back(float& dis) {
         if constexpr (NH == 1) add<0>(dis);
@@ -110,7 +113,9 @@ template <int M> struct ScanMShape {
     // tools/micro/lds_gather.hip), k = 100 1.75 -> 1.62 / 1.21, k = 200 2.5 -> 1.66; a 1250-query slice loses 8 % (0.222 -> 0.242).
     // 8-byte codes with 2 waves measured slower (0.371 -> 0.388).  64-byte codes with 16 waves and 16 entries per thread
     // measured 3.92 / 4.25 ms on the two bench data sets against 3.82 / 4.00 with 8 waves and 32 entries per thread -- 145
-    // VGPRs, one workgroup per CU either way; forcing 128 VGPRs for two workgroups spills: 4.41 / 3.81.
+    // VGPRs, one workgroup per CU either way; forcing 128 VGPRs for two workgroups spills: 4.41 / 3.81 (round 5, with the
+    // chunks requested a probe ahead: 3.62 / 3.77 at one workgroup, 4.05 / 3.34 forced to two -- the headline data's 64 KB rows,
+    // 21 GB requested per launch, are what bounds it: more workgroups in flight only lower the L2 hit rate).
     static constexpr int NW = M <= 32 ? 4 : 8;
     static constexpr int NT = 64 * NW;
     static constexpr int E = M * 256;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64 * (NWX ? NWX : ScanMShape<M>::NW)) __attribute__
     #ifdef VLQ_SCANM8_OLD
     constexpr bool AHEAD = DSUB == 0 && KPL <= 2 && M == 32;
 #else
-    constexpr bool AHEAD = DSUB == 0 && KPL <= 2 && M <= 32;
+    constexpr bool AHEAD = DSUB == 0 && KPL <= 2;
 #endif
     constexpr int DEPTH = (AHEAD && NBUF == 2) ? 2 : 1;
     constexpr int NPRE = M == 8 ? 3 : 2;           // chunks of a list requested ahead (32-byte codes: registers)
