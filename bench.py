@@ -834,10 +834,13 @@ def main():
                      "algorithmic_bytes": code_bytes,
                      "lut_bytes_separate": lut_bytes,
                      "lut_plus_code_GBps": (code_bytes + lut_bytes) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
-                     # what actually bounds this kernel: one random 32-bit LDS gather per code byte.  Peak = the measured
-                     # gather rate of the LDS pipe for uniformly random byte indices (tools/micro/lds_gather.hip: 9.98 lanes
-                     # per clock and CU at 16 waves per CU, 2.4 GHz nominal, 256 CUs; bank arithmetic: 64 / (2 x 3.15)) --
-                     # reported beside the HBM fraction the contract asks for
+                     # the kernel's other resource: one random 32-bit LDS gather per code byte.  Reference rate = the
+                     # measured gather rate of the LDS pipe for uniformly random byte indices (tools/micro/lds_gather.hip:
+                     # 9.98 lanes per clock and CU at 16 waves per CU, 2.4 GHz nominal, 256 CUs; bank arithmetic: 64 /
+                     # (2 x 3.15)); long-list data runs at 1.07 of it, so it is a yardstick, not a ceiling.  It is NOT what
+                     # bounds the headline shape: with every gather compiled out the kernel takes 0.512 ms against 0.520
+                     # (profiles/r05_scan16_phases.txt section 4: an LDS / issue floor of 0.43 ms and a fabric-traffic
+                     # floor of 0.485 ms overlap to 0.52) -- reported beside the HBM fraction the contract asks for
                      "lds_gather": {"achieved_per_clock_cu": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 if scan_ms > 0 else 0.0,
                                     "peak_per_clock_cu": 9.98,
                                     "frac": code_bytes / (scan_ms * 1e-3) / 256 / 2.4e9 / 9.98 if scan_ms > 0 else 0.0}},
