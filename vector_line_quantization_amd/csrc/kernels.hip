@@ -1616,10 +1616,118 @@ __global__ __launch_bounds__(NTH) void imi_minsum_lds_kernel(
     }
 }
 
+// The same walk by ONE WAVE per query with the heap in registers (round 5; k <= 64 and T <= 64: the heap never holds more than
+// 64 entries when a pop or a push needs it, see below).  The thread-per-query kernels above spend ~35 DEPENDENT memory round
+// trips per emitted cell and keep 313 half-empty waves on the chip for 10 000 queries: 209 us at nprobe 64, 41 % of the
+// multi-index coarse stage.  Here lane i holds heap node i + 1 and table entries v0[i], v1[i], x0[i], x1[i]; lane kk collects
+// output kk.  Heap.h:89-127's sift loops become
+//   push: the new slot's ancestors all compare with the value at once; the deepest ancestor that does not lose stops the
+//         sift, every path node below it takes its parent's entry, the topmost of them the new one;
+//   pop:  every node picks its smaller child at once (the reference's rule, incl. `i2 == k + 1`); a scalar walk from the root
+//         follows the picks while the last entry does not win; the nodes walked take their picked child's entry, the end of the
+//         walk the last one.
+// Same comparisons on the same values in the same heap positions => the same pops in the same order, ties included.
+// Measured (10 000 queries, 2 x 14 bits, nprobe 64): 209 -> 168 us.  It is bound by instruction issue now (~160 wave
+// instructions per emitted cell x 63 cells x 10 000 waves on 1024 SIMDs; trimming the shuffles' address arithmetic and the
+// per-cell key arithmetic did not move it: the scalar walk of the pop, ~10 instructions per heap level, is the bulk).
+// Size: two entries after the first cell, at most one more per emitted cell => at most kk + 1 before the pops of iteration kk
+// and kk + 2 after its pushes; the pushes of the last iteration feed nothing and are skipped, so <= 64 for k <= 64.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void imi_minsum_wave_kernel(
+    const float* __restrict__ sv0, const int64_t* __restrict__ si0, const float* __restrict__ sv1,
+    const int64_t* __restrict__ si1, int T, int64_t nq, int k, int kc, int imi_nbits,
+    float* __restrict__ sums, int64_t* __restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const bool in_t = lane < T;
+    const float v0 = in_t ? sv0[q * T + lane] : 0.f, v1 = in_t ? sv1[q * T + lane] : 0.f;
+    const int x0 = in_t ? (int)si0[q * T + lane] : 0, x1 = in_t ? (int)si1[q * T + lane] : 0;
+    auto rlf = [](float x, int l) __attribute__((always_inline)) {      // l wave-uniform
+        return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), l));
+    };
+    auto rli = [](int x, int l) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(x, l); };
+    float hv = 0.f;        // heap node lane + 1: value
+    int hid = 0;           // ... term (r0 | r1 << 16, as in the LDS kernel)
+    int n = 0;             // heap size (wave-uniform)
+    float os = 3.402823466e+38f;     // output slot `lane`: the sum and the term it belongs to (translated to a key at the end)
+    int oterm = -1;
+    const int pos = lane + 1;
+    // byte addresses of the lane permutations (ds_bpermute): parent, both children
+    const int a_par = ((pos >> 1) - 1) * 4, a_c1 = (2 * pos - 1) * 4, a_c2 = (2 * pos) * 4;
+    auto perm_f = [](int addr, float x) __attribute__((always_inline)) {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(x)));
+    };
+    auto push = [&](float val, int id) __attribute__((always_inline)) {
+        n++;
+        const int sh = __clz(pos) - __clz(n);                  // levels between this node and the new slot
+        const bool onp = sh >= 0 && (n >> sh) == pos;          // on the new slot's root path (the slot itself: sh = 0)
+        const u64 stopm = __ballot(onp && sh >= 1 && !(val < hv));
+        const int stop_pos = stopm ? 64 - (int)__clzll(stopm) : 0;      // deepest ancestor that stays (heap index; 0: none)
+        const float pv = perm_f(a_par, hv);
+        const int pid = __builtin_amdgcn_ds_bpermute(a_par, hid);
+        if (onp && pos > stop_pos) {
+            const bool topmost = (pos >> 1) == stop_pos;
+            hv = topmost ? val : pv;
+            hid = topmost ? id : pid;
+        }
+    };
+    auto pop = [&]() __attribute__((always_inline)) {
+        const float lastv = rlf(hv, n - 1);
+        const int lastid = rli(hid, n - 1);
+        const float cv1 = perm_f(a_c1, hv), cv2 = perm_f(a_c2, hv);
+        const int ci1 = __builtin_amdgcn_ds_bpermute(a_c1, hid), ci2 = __builtin_amdgcn_ds_bpermute(a_c2, hid);
+        const bool pick1 = (2 * pos + 1 == n + 1) || (cv1 < cv2);
+        const int cc = pick1 ? 2 * pos : 2 * pos + 1;
+        const float ccv = pick1 ? cv1 : cv2;
+        const int ccid = pick1 ? ci1 : ci2;
+        int cur = 1;
+        u64 walked = 0;
+        while (2 * cur <= n) {
+            const float v = rlf(ccv, cur - 1);
+            if (lastv < v) break;
+            walked |= 1ull << (cur - 1);
+            cur = rli(cc, cur - 1);
+        }
+        if ((walked >> lane) & 1ull) { hv = ccv; hid = ccid; }
+        if (lane == cur - 1) { hv = lastv; hid = lastid; }
+        n--;
+    };
+    const float sum = __fadd_rn(__fadd_rn(0.f, rlf(v0, 0)), rlf(v1, 0));
+    if (lane == 0) { os = sum; oterm = 0; }
+    if (T > 1 && k > 1) {
+        push(__fadd_rn(sum, __fsub_rn(rlf(v0, 1), rlf(v0, 0))), 1);
+        push(__fadd_rn(sum, __fsub_rn(rlf(v1, 1), rlf(v1, 0))), 1 << 16);
+    }
+    for (int kk = 1; kk < k; kk++) {
+        if (n == 0) break;                                      // fewer than k cells: the remaining slots keep FLT_MAX / -1
+        const float s2 = rlf(hv, 0);
+        const int ti = rli(hid, 0);
+        const int r0 = ti & 0xffff, r1 = ti >> 16;
+        if (lane == kk) { os = s2; oterm = ti; }
+        do { pop(); } while (n > 0 && rli(hid, 0) == ti);
+        if (kk == k - 1) break;                                 // (these pushes would feed nothing)
+        if (r0 + 1 < kc && r0 + 1 < T) push(__fadd_rn(s2, __fsub_rn(rlf(v0, r0 + 1), rlf(v0, r0))), ti + 1);
+        if (r1 + 1 < kc && r1 + 1 < T) push(__fadd_rn(s2, __fsub_rn(rlf(v1, r1 + 1), rlf(v1, r1))), ti + (1 << 16));
+    }
+    // the sub-quantizer indices behind the ranks of every output at once
+    const int tt = max(oterm, 0);
+    const int k0 = __builtin_amdgcn_ds_bpermute((tt & 0xffff) * 4, x0), k1 = __builtin_amdgcn_ds_bpermute((tt >> 16) * 4, x1);
+    const int64_t ok = oterm < 0 ? -1 : ((int64_t)k0 | ((int64_t)k1 << imi_nbits));
+    if (lane < k) { sums[q * k + lane] = os; keys[q * k + lane] = ok; }
+}
+
 void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, const int64_t* si1, int T,
                        int64_t nq, int k, int kc, int imi_nbits, float* heap_val, int64_t* heap_id,
                        float* sums, int64_t* keys, hipStream_t s) {
     if (nq <= 0) return;
+    static const bool no_wave = getenv("VLQ_IMI_MINSUM_LDS") != nullptr;       // (A/B: the thread-per-query walk)
+    if (k > 1 && k <= 64 && T <= 64 && kc <= 32768 && !no_wave) {
+        constexpr int NW = 4;
+        hipLaunchKernelGGL(imi_minsum_wave_kernel<NW>, dim3((unsigned)((nq + NW - 1) / NW)), dim3(64 * NW), 0, s,
+                           sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums, keys);
+        return;
+    }
     constexpr int NTH = 32;
     const size_t smem = (size_t)NTH * ((size_t)4 * k * 4 + (size_t)4 * T * 4);
     if (k > 1 && smem <= 128 * 1024 && kc <= 32768 && T <= 32768) {
