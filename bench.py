@@ -316,18 +316,21 @@ def vlq_traffic():
     """HBM bytes per launch of the VLQ scan from the filed counter passes -- quoted only while the kernel sources they were
     measured on are unchanged (same rule as the headline's roofline.traffic)."""
     import hashlib
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_vlq_traffic.json")) as fh:
-            rec = json.load(fh)
-        hh = hashlib.sha256()
-        for f in rec["sources"]:
-            with open(os.path.join(ROOT, "vector_line_quantization_amd", "csrc", f), "rb") as fh:
-                hh.update(fh.read())
-        if hh.hexdigest() != rec["sources_sha"]:
-            return {}
-        return {name: rec[name]["bytes"] for name in ("fp32_tables", "float16_tables")}
-    except (OSError, KeyError, ValueError):
-        return {}
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_vlq_traffic.json")), reverse=True):      # newest round first
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+            hh = hashlib.sha256()
+            for f in rec["sources"]:
+                with open(os.path.join(ROOT, "vector_line_quantization_amd", "csrc", f), "rb") as fh:
+                    hh.update(fh.read())
+            if hh.hexdigest() != rec["sources_sha"]:
+                continue
+            return {name: rec[name]["bytes"] for name in ("fp32_tables", "float16_tables")}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}
 
 
 def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5, nsample=64):
