@@ -91,15 +91,19 @@ template <int M> struct CodeWords { uint32_t w[M / 4]; };
 template <int M>
 __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ base, int64_t row) {
     CodeWords<M> c;
-    if (M == 8) {
-        const uint2 v = reinterpret_cast<const uint2*>(base)[row];
-        c.w[0] = v.x; c.w[1] = v.y;
-    } else {
+    if constexpr (M % 16 == 0) {
         const uint4* p = reinterpret_cast<const uint4*>(base) + row * (M / 16);
 #pragma unroll
         for (int i = 0; i < M / 16; i++) {
             const uint4 v = p[i];
             c.w[4 * i] = v.x; c.w[4 * i + 1] = v.y; c.w[4 * i + 2] = v.z; c.w[4 * i + 3] = v.w;
+        }
+    } else {                        // 8, 24, 40, 56 bytes: rows are 8-byte aligned
+        const uint2* p = reinterpret_cast<const uint2*>(base) + row * (M / 8);
+#pragma unroll
+        for (int i = 0; i < M / 8; i++) {
+            const uint2 v = p[i];
+            c.w[2 * i] = v.x; c.w[2 * i + 1] = v.y;
         }
     }
     return c;
@@ -568,7 +572,7 @@ bool scanm0_supports(const ScanArgs& a) {
 }
 
 bool scanm_supports(const ScanArgs& a) {
-    return (a.M == 8 || a.M == 32 || a.M == 64) && a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
+    return (a.M == 8 || a.M == 24 || a.M == 32 || a.M == 40 || a.M == 48 || a.M == 56 || a.M == 64) && a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
            a.nprobe <= 1024 &&
            (a.imi_nbits == 0 || a.M % 2 == 0);
 }
@@ -590,9 +594,17 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
         }
         return;
     }
-    if (a.M == 8) launch_scanm_k<8, 2>(a, s);
-    else if (a.M == 32) launch_scanm_k<32, 1>(a, s);     // one 32 KB buffer, 4 waves (ScanMShape)
-    else launch_scanm_k<64, 1>(a, s);
+    // (round 5: 24-, 40-, 48- and 56-byte codes -- the other multiples of 8 the reference instantiates, gpu/impl/IVFPQ.cu:149-172
+    // -- are the same template: M / 8 half blocks, one table buffer, 4 waves up to 32 bytes, 8 above)
+    switch (a.M) {
+    case 8: launch_scanm_k<8, 2>(a, s); break;
+    case 24: launch_scanm_k<24, 1>(a, s); break;
+    case 32: launch_scanm_k<32, 1>(a, s); break;      // one 32 KB buffer, 4 waves (ScanMShape)
+    case 40: launch_scanm_k<40, 1>(a, s); break;
+    case 48: launch_scanm_k<48, 1>(a, s); break;
+    case 56: launch_scanm_k<56, 1>(a, s); break;
+    default: launch_scanm_k<64, 1>(a, s); break;
+    }
 }
 
 }  // namespace vlq
