@@ -1,4 +1,4 @@
-"""GPU: the engineered scan for 8-, 24-, 32-, 40-, 48-, 56- and 64-byte codes (csrc/scanm.hip: the 16-byte kernel's organisation over the code
+"""GPU: the engineered scan for 4-, 8-, 12-, 20-, 24-, 28-, 32-, 40-, 48-, 56- and 64-byte codes (csrc/scanm.hip: the 16-byte kernel's organisation over the code
 sizes the reference instantiates, gpu/impl/IVFPQ.cu:149-172) against the oracle, bit for bit, and against the generic kernel
 (VLQ_GENERIC_SCAN) -- over the selection classes, short and long lists, empty lists, the max_codes cut, skipped / invalid
 probes, store_pairs, batches small enough to be split over workgroups, and the multi-index table type 2."""
@@ -35,7 +35,7 @@ def make(M, dsub, nlist, nb, seed, long_frac=0.0):
     return rng, ox, g, gen
 
 
-@pytest.mark.parametrize("M,dsub", [(8, 8), (8, 4), (32, 4), (32, 2), (64, 2), (64, 1), (24, 4), (40, 2), (48, 2), (56, 2)])
+@pytest.mark.parametrize("M,dsub", [(8, 8), (8, 4), (32, 4), (32, 2), (64, 2), (64, 1), (24, 4), (40, 2), (48, 2), (56, 2), (12, 8), (20, 4), (28, 4), (4, 8)])
 @pytest.mark.parametrize("nq,nprobe,k", [(1500, 16, 10), (40, 8, 1), (300, 32, 100), (1100, 24, 200), (64, 64, 1000)])
 def test_code_sizes_bit_exact(M, dsub, nq, nprobe, k):
     rng, ox, g, gen = make(M, dsub, 96, 12000, 100 * M + dsub, long_frac=0.3)
@@ -48,7 +48,7 @@ def test_code_sizes_bit_exact(M, dsub, nq, nprobe, k):
     assert g.stats(reset=True)[1] == ox.last_ncode if hasattr(ox, "last_ncode") else True
 
 
-@pytest.mark.parametrize("M,dsub", [(8, 8), (32, 4), (64, 2), (24, 4), (40, 2), (48, 2), (56, 2)])
+@pytest.mark.parametrize("M,dsub", [(8, 8), (32, 4), (64, 2), (24, 4), (40, 2), (48, 2), (56, 2), (12, 8), (20, 4), (28, 4), (4, 8)])
 def test_code_sizes_seam_holes_pairs_and_max_codes(M, dsub):
     rng, ox, g, gen = make(M, dsub, 64, 6000, 7 * M)
     xq = gen(700)
@@ -71,7 +71,7 @@ def test_code_sizes_seam_holes_pairs_and_max_codes(M, dsub):
         g.search_preassigned(xq, bad, cd, 5)
 
 
-@pytest.mark.parametrize("M", [8, 32, 24, 48])
+@pytest.mark.parametrize("M", [8, 32, 24, 48, 12, 28])
 def test_code_sizes_multi_index_table_type_2(M):
     """MultiIndexQuantizer coarse quantizer: term2 rows per coarse SUB-index, sub-quantizers of the first half of the code
     take theirs from the first sub-index (IndexIVFPQ.cpp:645-686) -- sift1b_imi_pq.cpp's index shape with 8-byte codes."""
@@ -130,7 +130,7 @@ import sys, json, numpy as np
 sys.path.insert(0, "tests")
 import test_gpu_code_sizes as t
 out = {}
-for M, dsub in ((8, 8), (32, 4), (64, 2), (24, 4), (40, 2), (48, 2), (56, 2)):
+for M, dsub in ((8, 8), (32, 4), (64, 2), (24, 4), (40, 2), (48, 2), (56, 2), (12, 8), (20, 4), (28, 4), (4, 8)):
     rng, ox, g, gen = t.make(M, dsub, 96, 12000, 100 * M + dsub, long_frac=0.3)
     xq = gen(600)
     D, I = g.search(xq, 16, 10)

@@ -54,7 +54,7 @@ def make(M, nlist, seed, twins):
     return rng, ox, g, d
 
 bad = []
-for M in (8, 16, 24, 32, 48):
+for M in (8, 12, 16, 24, 28, 32, 48):
     for twins in (False, True):
         for nlist, nprobe in ((32, 8), (2048, 16)):
             rng, ox, g, d = make(M, nlist, 17 * M + nlist + twins, twins)

@@ -21,7 +21,7 @@ for name, kw in (("headline", {}), ("G1", dict(sigma=0.03, rank=0, spread=0.0)))
     for M in [int(v) for v in os.environ.get("MS", "8,16,32,64").split(",")]:
         a = copy.copy(base)
         a.M = M
-        a.d = 128 if 128 % M == 0 else M * (128 // M)        # 24 / 40 / 48 / 56 bytes: d = 120 / 120 / 96 / 112
+        a.d = 128 if 128 % M == 0 else M * (128 // M)        # 12 / 20 / 24 / 28 / 40 / 48 / 56 bytes: d = 120 / 120 / 120 / 112 / 120 / 96 / 112
         for k_, v in kw.items():
             setattr(a, k_, v)
         g, centres, coarse, pq, xb = bench.build_index(a, dev)

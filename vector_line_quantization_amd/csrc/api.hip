@@ -410,7 +410,8 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
     const int64_t page = 32768;
     // M=16 x 8 bit x d=128 in table mode 1: the scan kernel builds the per-query table itself
     // (and the 8 / 32 / 64-byte kernels of scanm.hip, any dsub, when they will serve the batch)
-    const bool scanm_shape = table_mode == 1 && (h->M == 8 || (h->M >= 24 && h->M <= 64 && h->M % 8 == 0)) && h->ksub == 256 &&
+    const bool scanm_shape = table_mode == 1 && (h->M == 4 || h->M == 8 || h->M == 12 || (h->M >= 20 && h->M <= 32 && h->M % 4 == 0 && h->M != 16) ||
+                                                 (h->M >= 40 && h->M <= 64 && h->M % 8 == 0)) && h->ksub == 256 &&
                              h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN") && !getenv("VLQ_SCANM_QTAB");
     const bool fused_tables = (table_mode == 1 && h->M == 16 && h->ksub == 256 && h->dsub == 8) || scanm_shape;
     if (table_mode != 0 && !fused_tables)

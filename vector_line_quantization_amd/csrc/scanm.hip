@@ -32,27 +32,62 @@ template <int N>
 __device__ __forceinline__ void wait_hb(float (&v)[8]) {
     if (N == 0) VLQ_WAIT8(0, v); else VLQ_WAIT8(8, v);
 }
+// a last half block of FOUR sub-quantizers (12-, 20-, 28-byte codes: one word against four table slices)
+#define VLQ_G4_NWI(OFFS, W0)                                                                       \
+    asm volatile(                                                                          \
+        "v_lshlrev_b32_sdwa %0, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+        "v_lshlrev_b32_sdwa %1, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+        "v_lshlrev_b32_sdwa %2, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t" \
+        "v_lshlrev_b32_sdwa %3, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t" \
+        "ds_read_b32 %0, %0 offset:%6+0\n\t"                                               \
+        "ds_read_b32 %1, %1 offset:%6+1024\n\t"                                            \
+        "ds_read_b32 %2, %2 offset:%6+2048\n\t"                                            \
+        "ds_read_b32 %3, %3 offset:%6+3072"                                                 \
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])                               \
+        : "v"(W0), "v"(two), "n"(OFFS)                                                     \
+        : "memory")
+// sub-quantizers of half block S of an M-byte code, and the counted wait that says "half block S has arrived" while the next
+// one (if any) is still in flight
+template <int M> struct HbGeom {
+    static constexpr int NH = (M + 7) / 8;
+    static constexpr int size(int S) { return (S == NH - 1 && M % 8 == 4) ? 4 : 8; }
+};
 template <int M, int O, int S>
-__device__ __forceinline__ void adc_step(float (&hb)[M / 8][8], const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
-    constexpr int NH = M / 8;
-    wait_hb<(S == NH - 1) ? 0 : 8>(hb[S]);
+__device__ __forceinline__ void issue_hb_s(float (&v)[8], const uint32_t (&w)[M / 4], uint32_t two) {
+    if constexpr (HbGeom<M>::size(S) == 8) issue_hb<O + S * 8192>(v, w[2 * S], w[2 * S + 1], two);
+    else { VLQ_G4_NWI(O + S * 8192, w[2 * S]); }
+}
+template <int M, int S>
+__device__ __forceinline__ void wait_add_s(float (&v)[8], float& dis) {
+    constexpr int NH = HbGeom<M>::NH, N = HbGeom<M>::size(S);
+    constexpr int BEHIND = S == NH - 1 ? 0 : HbGeom<M>::size(S + 1);       // reads still in flight behind this half block
+    if constexpr (N == 8) {
+        if constexpr (BEHIND == 0) VLQ_WAIT8(0, v); else if constexpr (BEHIND == 4) VLQ_WAIT8(4, v); else VLQ_WAIT8(8, v);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+    }
 #pragma unroll
-    for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hb[S][m]);
+    for (int m = 0; m < N; m++) dis = __fadd_rn(dis, v[m]);
     asm volatile("" : "+v"(dis));
-    if constexpr (S + 2 < NH) issue_hb<O + (S + 2) * 8192>(hb[S + 2], w[2 * (S + 2)], w[2 * (S + 2) + 1], two);
+}
+template <int M, int O, int S>
+__device__ __forceinline__ void adc_step(float (&hb)[HbGeom<M>::NH][8], const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
+    constexpr int NH = HbGeom<M>::NH;
+    wait_add_s<M, S>(hb[S], dis);
+    if constexpr (S + 2 < NH) issue_hb_s<M, O, S + 2>(hb[S + 2], w, two);
     if constexpr (S + 1 < NH) adc_step<M, O, S + 1>(hb, w, dis, two);
 }
 
 // dis + the M table values of one code, left to right; the table sits at LDS byte offset O (compile time), w = the code's words.
-// Half blocks of 8 sub-quantizers (words 2h, 2h+1 against table slices 8h .. 8h+7): two in flight, the adds of one under the
-// reads of the next (lgkmcnt counts 16).
+// Half blocks of 8 sub-quantizers (words 2h, 2h+1 against table slices 8h .. 8h+7; the last one of a 12-, 20- or 28-byte code
+// has 4): two in flight, the adds of one under the reads of the next (counted lgkmcnt).
 template <int M, int O>
 __device__ __forceinline__ float adc_m(const uint32_t (&w)[M / 4], float dis, uint32_t two) {
-    constexpr int NH = M / 8;
+    constexpr int NH = HbGeom<M>::NH;
     static_assert(O + (NH - 1) * 8192 + 7168 < 65536, "ds_read offsets are 16 bits");
     float hb[NH][8];
-    issue_hb<O>(hb[0], w[0], w[1], two);
-    if constexpr (NH > 1) issue_hb<O + 8192>(hb[1], w[2], w[3], two);
+    issue_hb_s<M, O, 0>(hb[0], w, two);
+    if constexpr (NH > 1) issue_hb_s<M, O, 1>(hb[1], w, two);
     adc_step<M, O, 0>(hb, w, dis, two);
     return dis;
 }
@@ -61,24 +96,19 @@ __device__ __forceinline__ float adc_m(const uint32_t (&w)[M / 4], float dis, ui
 // turned into addresses, its registers may be reloaded (the scan requests the next list's chunk there) -- back() adds the last
 // two half blocks.  Same order of the additions, same counted waits.
 template <int M, int O> struct AdcSplit {
-    static constexpr int NH = M / 8;
+    static constexpr int NH = HbGeom<M>::NH;
     float hb[NH][8];
-    template <int S> __device__ __forceinline__ void add(float& dis) {
-        wait_hb<(S == NH - 1) ? 0 : 8>(hb[S]);
-#pragma unroll
-        for (int m = 0; m < 8; m++) dis = __fadd_rn(dis, hb[S][m]);
-        asm volatile("" : "+v"(dis));
-    }
+    template <int S> __device__ __forceinline__ void add(float& dis) { wait_add_s<M, S>(hb[S], dis); }
     template <int S> __device__ __forceinline__ void roll(const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
         if constexpr (S + 2 < NH) {
             add<S>(dis);
-            issue_hb<O + (S + 2) * 8192>(hb[S + 2], w[2 * (S + 2)], w[2 * (S + 2) + 1], two);
+            issue_hb_s<M, O, S + 2>(hb[S + 2], w, two);
             roll<S + 1>(w, dis, two);
         }
     }
     __device__ __forceinline__ void front(const uint32_t (&w)[M / 4], float& dis, uint32_t two) {
-        issue_hb<O>(hb[0], w[0], w[1], two);
-        if constexpr (NH > 1) issue_hb<O + 8192>(hb[1], w[2], w[3], two);
+        issue_hb_s<M, O, 0>(hb[0], w, two);
+        if constexpr (NH > 1) issue_hb_s<M, O, 1>(hb[1], w, two);
         roll<0>(w, dis, two);
     }
     __device__ __forceinline__ void back(float& dis) {
@@ -98,13 +128,17 @@ __device__ __forceinline__ CodeWords<M> load_code(const uint8_t* __restrict__ ba
             const uint4 v = p[i];
             c.w[4 * i] = v.x; c.w[4 * i + 1] = v.y; c.w[4 * i + 2] = v.z; c.w[4 * i + 3] = v.w;
         }
-    } else {                        // 8, 24, 40, 56 bytes: rows are 8-byte aligned
+    } else if constexpr (M % 8 == 0) {      // 8, 24, 40, 56 bytes: rows are 8-byte aligned
         const uint2* p = reinterpret_cast<const uint2*>(base) + row * (M / 8);
 #pragma unroll
         for (int i = 0; i < M / 8; i++) {
             const uint2 v = p[i];
             c.w[2 * i] = v.x; c.w[2 * i + 1] = v.y;
         }
+    } else {                                // 12, 20, 28 bytes: 4-byte aligned
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + row * (M / 4);
+#pragma unroll
+        for (int i = 0; i < M / 4; i++) c.w[i] = p[i];
     }
     return c;
 }
@@ -572,7 +606,8 @@ bool scanm0_supports(const ScanArgs& a) {
 }
 
 bool scanm_supports(const ScanArgs& a) {
-    return (a.M == 8 || a.M == 24 || a.M == 32 || a.M == 40 || a.M == 48 || a.M == 56 || a.M == 64) && a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
+    return (a.M == 4 || a.M == 8 || a.M == 12 || (a.M >= 20 && a.M <= 32 && a.M % 4 == 0) || (a.M >= 40 && a.M <= 64 && a.M % 8 == 0)) &&
+           a.ksub == 256 && a.table_mode == 1 && (a.qtab || a.pq_cent_t) && a.term2 &&
            a.nprobe <= 1024 &&
            (a.imi_nbits == 0 || a.M % 2 == 0);
 }
@@ -594,11 +629,16 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
         }
         return;
     }
-    // (round 5: 24-, 40-, 48- and 56-byte codes -- the other multiples of 8 the reference instantiates, gpu/impl/IVFPQ.cu:149-172
-    // -- are the same template: M / 8 half blocks, one table buffer, 4 waves up to 32 bytes, 8 above)
+    // (round 5: 4-, 12-, 20-, 24-, 28-, 40-, 48- and 56-byte codes -- the other multiples of 4 bytes that the reference
+    // instantiates, gpu/impl/IVFPQ.cu:149-172 -- are the same template: ceil(M / 8) half blocks, the last one of 4 where M is
+    // not a multiple of 8, one table buffer, 4 waves up to 32 bytes, 8 above)
     switch (a.M) {
     case 8: launch_scanm_k<8, 2>(a, s); break;
+    case 4: launch_scanm_k<4, 1>(a, s); break;
+    case 12: launch_scanm_k<12, 1>(a, s); break;
+    case 20: launch_scanm_k<20, 1>(a, s); break;
     case 24: launch_scanm_k<24, 1>(a, s); break;
+    case 28: launch_scanm_k<28, 1>(a, s); break;
     case 32: launch_scanm_k<32, 1>(a, s); break;      // one 32 KB buffer, 4 waves (ScanMShape)
     case 40: launch_scanm_k<40, 1>(a, s); break;
     case 48: launch_scanm_k<48, 1>(a, s); break;
