@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def draw(seed):
     rng = np.random.default_rng(1000 + seed)
-    M = int(rng.choice([1, 2, 3, 4, 8, 8, 16, 16, 16, 32, 32, 64]))    # 8 / 32 / 64 x 8 bit in table mode 1: scanm.hip
+    M = int(rng.choice([1, 2, 3, 4, 4, 8, 8, 12, 16, 16, 16, 20, 24, 28, 32, 32, 40, 48, 56, 64]))    # multiples of 4 (but 16) x 8 bit in table mode 1: scanm.hip
     dsub = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 12]))
     if M == 16 and rng.random() < 0.5:
         dsub = int(rng.choice([6, 8]))                       # the 16-byte fast path, both table sources

@@ -3,7 +3,7 @@
 ~330 codes per visited list) and G1 (sigma 0.03, ~700 codes per visited list), 10 000 queries, nprobe 32, k 10.  Per size:
 stage times from the library's HIP events, and the scan's rate as a fraction of the LDS gather ceiling (one random 4-byte
 LDS gather per code byte: 9.98 lanes per clock and CU, tools/micro/lds_gather.hip) and of the HBM peak (code bytes).
-   python tools/time_code_sizes.py [reps]      env: MS=8,16,32,64  SETS=headline,G1  GENERIC=1 (the generic kernel, via VLQ_GENERIC_SCAN)"""
+   python tools/time_code_sizes.py [reps]      env: MS=4,8,...,64 (default: every engineered size)  SETS=headline,G1  GENERIC=1 (the generic kernel, via VLQ_GENERIC_SCAN)"""
 import argparse, copy, os, sys
 if os.environ.get("GENERIC"):
     os.environ["VLQ_GENERIC_SCAN"] = "1"
@@ -18,7 +18,7 @@ base = argparse.Namespace(nq=10000, nb=1000000, nt=100000, d=128, nlist=4096, M=
 for name, kw in (("headline", {}), ("G1", dict(sigma=0.03, rank=0, spread=0.0))):
     if name not in os.environ.get("SETS", "headline,G1").split(","):
         continue
-    for M in [int(v) for v in os.environ.get("MS", "8,16,32,64").split(",")]:
+    for M in [int(v) for v in os.environ.get("MS", "4,8,12,16,20,24,28,32,40,48,56,64").split(",")]:
         a = copy.copy(base)
         a.M = M
         a.d = 128 if 128 % M == 0 else M * (128 // M)        # 12 / 20 / 24 / 28 / 40 / 48 / 56 bytes: d = 120 / 120 / 120 / 112 / 120 / 96 / 112
