@@ -455,12 +455,12 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
         // admission bound than the rows save: k = 100 0.81 -> 0.84 ms), nprobe >= 16, 8- (two-wave shape, from 3000 queries on:
         // 0.366 -> 0.343 ms on the headline data, 2.15 -> 1.70 GB fetched; four waves 0.356 -> 0.359), every engineered size from
         // 12 to 56 bytes (12 / 20 / 24 / 28 / 40 / 48 / 56 bytes: 0.53 / 0.92 / 1.14 / 1.37 / 1.96 / 2.37 / 2.80 -> 0.47 / 0.82 /
-        // 1.00 / 1.23 / 1.78 / 2.13 / 2.55 ms; 64-byte codes at one workgroup per CU measured no gain), and only when the batch's
+        // 1.00 / 1.23 / 1.78 / 2.13 / 2.55 ms forced, more with the measured clock period; 64-byte codes 3.61 -> 3.47), and only when the batch's
         // neighbours share few lists
         // (walk_stat_kernel below).  VLQ_WALK_FIRST = n forces n probes in front for every batch, -1 the reference's order.
         static const int wf_env = [] { const char* e = getenv("VLQ_WALK_FIRST"); return e ? atoi(e) : -2; }();
         const bool walk_base = table_mode == 1 && h->imi_nbits == 0 &&
-                               ((h->M >= 12 && h->M <= 56 && h->M % 4 == 0) || (h->M == 8 && ni >= 3000)) &&
+                               ((h->M >= 12 && h->M <= 64 && h->M % 4 == 0) || (h->M == 8 && ni >= 3000)) &&
                                h->ksub == 256 && ni >= 1024 && !h->fp16_tables;
         // k <= 64 from 16 probes on; 64 < k <= 128 from 64 probes on with the 4 nearest in front (headline data, nprobe 64,
         // k 100: 1.51 -> 1.38 ms; at nprobe 32 nothing to gain: 0.81 = 0.81) on indexes of short lists
