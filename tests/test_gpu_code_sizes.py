@@ -94,7 +94,7 @@ def test_code_sizes_multi_index_table_type_2(M):
         assert np.array_equal(bits(D), bits(Do)) and np.array_equal(I, Io)
 
 
-@pytest.mark.parametrize("M,dsub", [(16, 8), (16, 6), (16, 4), (8, 16), (8, 12), (8, 8)])
+@pytest.mark.parametrize("M,dsub", [(16, 8), (16, 6), (16, 4), (8, 16), (8, 12), (8, 8), (32, 4), (32, 2)])
 @pytest.mark.parametrize("nq,nprobe,k", [(1500, 16, 10), (40, 8, 1), (300, 33, 100), (64, 64, 300)])
 def test_table_mode_0_bit_exact(M, dsub, nq, nprobe, k):
     """by_residual WITHOUT the precomputed table (use_precomputed_table = 0: GpuIndexIVFPQConfig's default; IndexIVFPQ.cpp:

@@ -597,12 +597,13 @@ static void launch_scanm_k(const ScanArgs& a, hipStream_t s) {
 #undef VLQ_SM
 }
 
-// table mode 0 on the engineered kernel: 8- and 16-byte codes, flat coarse quantizer, d <= 128 (a thread holds d codebook floats)
+// table mode 0 on the engineered kernel: 8-, 16- and 32-byte codes, flat coarse quantizer, d <= 128 (a thread holds d codebook floats)
 bool scanm0_supports(const ScanArgs& a) {
     if (!(a.table_mode == 0 && a.ksub == 256 && a.imi_nbits == 0 && a.coarse && a.pq_cent && a.queries && a.nprobe <= 1024)) return false;
     if (a.M == 16) return a.dsub == 4 || a.dsub == 6 || a.dsub == 8;
     if (a.M == 8) return a.dsub == 8 || a.dsub == 12 || a.dsub == 16;
-    return false;
+    if (a.M == 32) return a.dsub == 2 || a.dsub == 4;         // (round 5: d = 64 / 128; 64-byte codes would put the second table
+    return false;                                             //  buffer past the 16-bit offset of the gather instructions)
 }
 
 bool scanm_supports(const ScanArgs& a) {
@@ -622,6 +623,9 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
             if (a.dsub == 8) launch_scanm0_k<16, 8>(a, s);
             else if (a.dsub == 6) launch_scanm0_k<16, 6>(a, s);
             else launch_scanm0_k<16, 4>(a, s);
+        } else if (a.M == 32) {
+            if (a.dsub == 4) launch_scanm0_k<32, 4>(a, s);
+            else launch_scanm0_k<32, 2>(a, s);
         } else {
             if (a.dsub == 16) launch_scanm0_k<8, 16>(a, s);
             else if (a.dsub == 12) launch_scanm0_k<8, 12>(a, s);
