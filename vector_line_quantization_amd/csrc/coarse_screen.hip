@@ -55,15 +55,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // components 16 ks + 8 h .. + 7 = one 16-byte load): no LDS, no barrier.  The kernel is bound by the matrix it writes.
 // tmin != nullptr (rows wider than 8192 columns): also the minimum of every 64-column tile of a row, [nq][nlist / 64];
 // out == nullptr: ONLY those minima, in fp32 (the 1-NN screen of the assignment).
-// BITS (the matrix-free screen, round 5): no matrix and no minima -- one bit per element, "approximate distance <= trow[row]",
-// bits[row][col / 32]: a wave's ballot over a register of the accumulator is 32 columns of two rows, so every (row, 32-column)
-// word is written whole by one wave, no atomics.  5 MB instead of the 82 MB half matrix at 10 000 x 4096.
-template <int KS, bool BITS = false>
+// (A bit-epilogue form of this kernel -- one bit per element under the row's bound instead of the matrix -- was the first
+// matrix-free pass of round 5; coarse_f16_stream_kernel below replaced it, docs/EXPERIMENTS.md.)
+template <int KS>
 __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                               const float* __restrict__ qn, const float* __restrict__ cn,
                                                               _Float16* __restrict__ out, int64_t nq, int nlist, float inv_s2,
-                                                              float sd, float* __restrict__ tmin, const float* __restrict__ trow = nullptr,
-                                                              uint32_t* __restrict__ bits = nullptr) {
+                                                              float sd, float* __restrict__ tmin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + (wave >> 1) * 64;
@@ -91,42 +89,6 @@ __global__ __launch_bounds__(256) void coarse_f16_dist_kernel(const _Float16* __
             const int64_t row = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             qnr[rb][reg] = qn[row < nq ? row : nq - 1];
         }
-    if (BITS) {
-        // the same approximate distance as the minima pass (identical operations: a column at the row's cut passes its own
-        // test); lane L of wq[rb] collects the word of (row L >> 1 of the block, 32-column half L & 1)
-        const int nw = nlist >> 5;
-#pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
-            float tr[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int64_t row = row0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                tr[reg] = trow[row < nq ? row : nq - 1];
-            }
-            uint32_t wq = 0;
-#pragma unroll
-            for (int cb = 0; cb < 2; cb++) {
-                f32x16 acc;
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) acc[reg] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][ks], b[cb][ks], acc, 0, 0, 0);
-                const float cnv = cn[col0 + cb * 32 + r];
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    const float v = __fsub_rn(__fadd_rn(qnr[rb][reg], cnv), __fmul_rn(2.f, __fmul_rn(acc[reg], inv_s2)));
-                    const u64 m = __ballot(v <= tr[reg]);          // (false for NaN)
-                    const int rl = (reg & 3) + 8 * (reg >> 2);     // row of the lower half wave; the upper half's is rl + 4
-                    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);         // (wave-uniform: scalar registers)
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wq) : "s"(mlo), "n"(2 * rl + cb));
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(wq) : "s"(mhi), "n"(2 * (rl + 4) + cb));
-                }
-            }
-            const int64_t row = row0 + rb * 32 + (lane >> 1);
-            if (row < nq) bits[row * nw + (col0 >> 5) + (lane & 1)] = wq;
-        }
-        return;
-    }
 #pragma unroll
     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
