@@ -38,8 +38,8 @@ xq[:nself] = first[:nself]                              # half the batch: stored
 D = torch.empty((nq, k), dtype=torch.float32, device="cuda"); I = torch.empty((nq, k), dtype=torch.int64, device="cuda")
 for _ in range(2): g.search(xq, nprobe, k, D=D, I=I)
 torch.cuda.synchronize()
-g.stats(reset=True); g.profile(True); g.profile_read(reset=True)
-t0 = time.time(); reps = 5
+g.stats(reset=True); g.profile(not os.environ.get("NOPROF")); g.profile_read(reset=True)      # NOPROF=1: no stage events (the two halves of the coarse stage then run on two streams)
+t0 = time.time(); reps = 20 if os.environ.get("NOPROF") else 5
 for _ in range(reps): g.search(xq, nprobe, k, D=D, I=I)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps

@@ -282,7 +282,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     const int64_t n_pad = (n + 127) / 128 * 128;
     const size_t b_tab = (size_t)n_pad * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
     const size_t b_hv = (size_t)n * 2 * k * 4, b_hi = (size_t)n * 2 * k * 8, b_sub = (size_t)n * dc * 4;
-    TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + b_sub + 256));
+    TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + 2 * b_sub + 256));
     char* p = h->ws_imi.as<char>();
     float* tab[2] = {(float*)p, (float*)(p + b_tab)};
     p += 2 * b_tab;
@@ -295,6 +295,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     float* hv = (float*)p;
     p += b_hv;
     float* sub = (float*)p;
+    float* sub2 = (float*)(p + b_sub);
     if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
@@ -324,24 +325,57 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
         }
         if (dc >= 16 && h->coarse_screen && h->imi_screen[m].ok && n >= 2048 && vlq::coarse_screen_shape_ok(kc, dc, T)) {
             // float16 screen of this half's table (coarse_screen.hip): approximate half matrix in tab[m], kept columns, exact
-            // fmaf chains, exact select -- the T nearest sub-centroids and their distances as the matrix path returns them
+            // fmaf chains, exact select -- the T nearest sub-centroids and their distances as the matrix path returns them.
+            // Round 5: the two halves are independent chains of six latency-bound kernels (~140 us each at 2 x 14 bits); the
+            // second runs beside the first on an auxiliary stream with its own per-half workspaces, joined before the MinSumK
+            // replay.
             const vlq_ivfpq_s::ScreenSet& sc = h->imi_screen[m];
             const int dp = (dc + 15) / 16 * 16;
+            static const bool one_stream = getenv("VLQ_IMI_ONE_STREAM") != nullptr;
+            const bool aux = m == 1 && !one_stream && !h->prof && h->imi_screen[0].ok && dc >= 16;
             TRY(screen_counters(h));
-            TRY(h->ws_xh.reserve((size_t)n_pad * dp * 2));
-            TRY(h->ws_xflags.reserve((size_t)n));
-            TRY(h->ws_qn.reserve((size_t)n * 4));
-            TRY(h->ws_qn_c.reserve((size_t)n * 4));
-            TRY(h->ws_cand.reserve(vlq::coarse_screen_keep_bytes(n, kc)));
-            if (kc > 8192 || vlq::coarse_screen_matrix_free_ok(kc, T)) TRY(h->ws_tmin.reserve((size_t)n * (kc / 16 + 32) * sizeof(float)));
-            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, sub, h->stream);
-            vlq::launch_screen_prep(sub, sc.mu.as<float>(), n, dc, sc.scale, h->ws_xh.p, h->ws_qn.as<float>(), h->ws_qn_c.as<float>(),
-                                    h->ws_xflags.as<unsigned char>(), h->stream);
-            vlq::launch_coarse_screened(sub, h->ws_xh.p, h->ws_xflags.as<unsigned char>(), cent, sc.half.p, h->ws_qn.as<float>(),
-                                        h->imi_norm.as<float>() + (size_t)m * kc, h->ws_qn_c.as<float>(), sc.norm_c.as<float>(), tab[m],
-                                        h->ws_tmin.p ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
-                                        h->ws_screen_cnt.as<unsigned int>(), h->stream);
-            TRY(screen_counters_copy(h, n));
+            DevBuf& b_xh = aux ? h->imi_ws2.xh : h->ws_xh;
+            DevBuf& b_xflags = aux ? h->imi_ws2.xflags : h->ws_xflags;
+            DevBuf& b_qn = aux ? h->imi_ws2.qn : h->ws_qn;
+            DevBuf& b_qn_c = aux ? h->imi_ws2.qn_c : h->ws_qn_c;
+            DevBuf& b_cand = aux ? h->imi_ws2.cand : h->ws_cand;
+            DevBuf& b_tmin = aux ? h->imi_ws2.tmin : h->ws_tmin;
+            float* subm = aux ? sub2 : sub;
+            TRY(b_xh.reserve((size_t)n_pad * dp * 2));
+            TRY(b_xflags.reserve((size_t)n));
+            TRY(b_qn.reserve((size_t)n * 4));
+            TRY(b_qn_c.reserve((size_t)n * 4));
+            TRY(b_cand.reserve(vlq::coarse_screen_keep_bytes(n, kc)));
+            if (kc > 8192 || vlq::coarse_screen_matrix_free_ok(kc, T)) TRY(b_tmin.reserve((size_t)n * (kc / 16 + 32) * sizeof(float)));
+            hipStream_t st = h->stream;
+            if (aux) {
+                if (!h->imi_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&h->imi_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&h->imi_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&h->imi_join, hipEventDisableTiming));
+                }
+                st = h->imi_stream;
+                HIP_TRY(hipStreamWaitEvent(st, h->imi_fork, 0));        // (recorded before half 0 was issued: inputs and workspace ready)
+            } else if (m == 0 && !one_stream && !h->prof && h->imi_screen[1].ok) {
+                if (!h->imi_stream) {
+                    HIP_TRY(hipStreamCreateWithFlags(&h->imi_stream, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&h->imi_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&h->imi_join, hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventRecord(h->imi_fork, h->stream));
+            }
+            vlq::launch_gather_cols(x_dev, n, h->d, m * dc, dc, subm, st);
+            vlq::launch_screen_prep(subm, sc.mu.as<float>(), n, dc, sc.scale, b_xh.p, b_qn.as<float>(), b_qn_c.as<float>(),
+                                    b_xflags.as<unsigned char>(), st);
+            vlq::launch_coarse_screened(subm, b_xh.p, b_xflags.as<unsigned char>(), cent, sc.half.p, b_qn.as<float>(),
+                                        h->imi_norm.as<float>() + (size_t)m * kc, b_qn_c.as<float>(), sc.norm_c.as<float>(), tab[m],
+                                        b_tmin.p ? b_tmin.as<float>() : nullptr, b_cand.p, n, kc, dc, T, sc.scale, sc.cmax, sc.cmax0, sv[m], si[m], nullptr,
+                                        h->ws_screen_cnt.as<unsigned int>(), st);
+            if (aux) {
+                HIP_TRY(hipEventRecord(h->imi_join, st));
+                HIP_TRY(hipStreamWaitEvent(h->stream, h->imi_join, 0));
+            }
+            if (m == 1) TRY(screen_counters_copy(h, 2 * n));
             continue;
         }
         if (dc < 16) {
@@ -832,6 +866,10 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
         fprintf(stderr, "[vlq] coarse screen: %llu columns kept in total\n", kept);
         h->ws_kept.release();
     }
+    for (DevBuf* b : {&h->imi_ws2.xh, &h->imi_ws2.xflags, &h->imi_ws2.qn, &h->imi_ws2.qn_c, &h->imi_ws2.cand, &h->imi_ws2.tmin}) b->release();
+    if (h->imi_fork) (void)hipEventDestroy(h->imi_fork);
+    if (h->imi_join) (void)hipEventDestroy(h->imi_join);
+    if (h->imi_stream) (void)hipStreamDestroy(h->imi_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

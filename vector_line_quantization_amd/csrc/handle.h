@@ -118,6 +118,11 @@ struct vlq_ivfpq_s {
     struct ScreenSet { DevBuf half, mu, norm_c; float scale = 1.f, cmax = 0.f, cmax0 = 0.f; bool ok = false; };
     ScreenSet screen, imi_screen[2];
     DevBuf ws_qn_c, ws_xh, ws_xflags, ws_kept, ws_screen_cnt;
+    // second half of a multi-index coarse stage, screened beside the first on an auxiliary stream (imi_page): its own copies
+    // of the per-half workspaces, the stream, fork / join events
+    struct HalfWs { DevBuf xh, xflags, qn, qn_c, cand, tmin; } imi_ws2;
+    hipStream_t imi_stream = nullptr;
+    hipEvent_t imi_fork = nullptr, imi_join = nullptr;
     // rows the screen could not decide (too many / too few columns kept -> done exactly, slowly): counted on the device, mirrored
     // into page-locked memory by an asynchronous copy after every batch and looked at before the next -- an index whose data
     // defeat the bound (0.5 % of the rows) goes back to the matrix path for good
