@@ -1,17 +1,22 @@
-// List scan for 8-bit codes of 8, 32 and 64 bytes (M sub-quantizers x 256 centroids, precomputed-table mode 1 or 2): the
-// organisation of scan16_kernel (scan16.hip) over the code size.  The reference instantiates its scan per code size
-// (gpu/impl/IVFPQ.cu:149-172, PQScanMultiPassPrecomputed.cu:1299-1313, loads in PQCodeLoad.cuh:60-357); its CPU scan is one
-// loop over M (IndexIVFPQ.cpp:781-802).  Same arithmetic as the generic kernel in kernels.hip -- sim_table = term2[key] +
+// List scan for 8-bit codes of every size from 4 to 64 bytes that is a multiple of 4, except 16 (M sub-quantizers x 256
+// centroids, precomputed-table mode 1 or 2; mode 0 for 8- / 16- / 32-byte codes): the organisation of scan16_kernel
+// (scan16.hip) over the code size.  The reference instantiates its scan per code size (gpu/impl/IVFPQ.cu:149-172,
+// PQScanMultiPassPrecomputed.cu:1299-1313, loads in PQCodeLoad.cuh:60-357); its CPU scan is one loop over M
+// (IndexIVFPQ.cpp:781-802).  Same arithmetic as the generic kernel in kernels.hip -- sim_table = term2[key] +
 // (-2) * sim_table_2 (fvec_madd, IndexIVFPQ.cpp:641-644), dis = dis0 + tab[0][c0] + ... + tab[M-1][c_{M-1}] strictly left to
 // right (:788-794) -- so results cannot depend on which kernel served a query; what changes is how the work is laid out:
 //   * probe metadata gathered once per query into LDS, walking order without dead probes (ProbeMeta, scan16_common.cuh);
-//   * the table has M x 256 entries = M KB: 4 waves per workgroup up to 32 bytes, 8 for 64 (ScanMShape): a thread owns 8
-//     (M = 8), 16 or 32 (M = 32, 64) table entries;
-//   * term2[key] and every lane's first code are requested one live probe ahead, the next chunk of a list before the current one
-//     is consumed; one workgroup barrier per probe with two table buffers (M <= 16), two with one (M = 32, 64);
-//   * gathers in half blocks of 8 sub-quantizers: one SDWA op per code byte (byte extract and x4), sub-quantizer and buffer
-//     offsets in the ds_read offset field, two half blocks in flight while the previous one is added;
-//   * XCD-aware placement of the sorted query order, shared admission threshold of the workgroup's waves.
+//   * the table has M x 256 entries = M KB: 4 waves per workgroup up to 32 bytes, 8 above (ScanMShape; 8-byte codes: 2 waves
+//     from 3000 queries on): a thread owns M x 256 / threads table entries;
+//   * (round 5) a list's chunks are requested a whole probe ahead into the registers the trip that consumed them has freed,
+//     term2[key] behind the first chunk, every load of a probe unconditional and in one place (exact vmcnt counts); 8-byte codes
+//     two probes ahead with two register sets; one workgroup barrier per probe with two table buffers (8-byte codes, mode 0),
+//     two with one;
+//   * gathers in half blocks of 8 sub-quantizers (a last one of 4 for 4-, 12-, 20-, 28-byte codes): one SDWA op per code byte
+//     (byte extract and x4), sub-quantizer and buffer offsets in the ds_read offset field, two half blocks in flight while the
+//     previous one is added;
+//   * XCD-aware placement of the sorted query order, shared admission threshold of the workgroup's waves, keyed admission
+//     (wave_topk.cuh: equal distances keep the reference's scan order).
 #include <type_traits>
 
 #include "kernels.h"
