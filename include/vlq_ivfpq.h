@@ -47,6 +47,9 @@ enum {
 
 #define VLQ_MAX_K 1024        /* gpu/impl/IVFPQ.cu:966-967 */
 #define VLQ_MAX_NPROBE 1024
+/* coarse stage of a multi-index quantizer (vlq_ivfpq_set_imi_centroids): MultiIndexQuantizer::search has no limit on k
+ * (IndexPQ.cpp:804-857) and the reference's own drivers ask for 2048 cells (tests/sift1b_imi_pq.cpp:363) */
+#define VLQ_MAX_IMI_NPROBE 4096
 
 int vlq_version(void);
 const char* vlq_last_error(void);
@@ -153,7 +156,8 @@ int vlq_ivfpq_set_coarse_screen(vlq_ivfpq_t h, int mode);
 int vlq_ivfpq_coarse_screen_state(vlq_ivfpq_t h, int* enabled, uint64_t* rows, uint32_t* undecided);
 
 /* IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081) = GpuIndexIVFPQ::search.
- * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024, k <= 1024.
+ * x[n*d], D[n*k], I[n*k]   [h|d].   nprobe <= 1024 (multi-index quantizer: <= VLQ_MAX_IMI_NPROBE, scanned in runs of 1024
+ * like vlq_ivfpq_search_preassigned below; max_codes must be 0 then), k <= 1024.
  * Host D / I: the call returns with the rows in place.  PAGE-LOCKED host D / I (hipHostMalloc / hipHostRegister:
  * what GpuResources::getPinnedMemory hands out, gpu/GpuResources.h:40) are written by the scan kernel itself --
  * no staging buffer, no copy-out; pageable ones are staged through device memory and copied. */
@@ -174,8 +178,9 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
                                  const float* coarse_dis, int nprobe, int k, float* D,
                                  int64_t* I, int store_pairs);
 
-/* quantizer->search (IndexIVFPQ.cpp:1073 -> IndexFlat.cpp:42-56): top-nprobe
- * coarse centroids, ascending.  Outputs [h|d]. */
+/* quantizer->search (IndexIVFPQ.cpp:1073 -> IndexFlat.cpp:42-56; MultiIndexQuantizer::search IndexPQ.cpp:804-857):
+ * top-nprobe coarse centroids, ascending (multi-index: the cells in MinSumK's order, nprobe <= VLQ_MAX_IMI_NPROBE).
+ * Outputs [h|d]. */
 int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe,
                             float* coarse_dis, int64_t* keys);
 

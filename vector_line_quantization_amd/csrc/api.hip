@@ -281,7 +281,9 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     // workspace: 2 tables [n][kc] | sorted values 2x[n][T] | sorted ids 2x[n][T] | heap
     const int64_t n_pad = (n + 127) / 128 * 128;
     const size_t b_tab = (size_t)n_pad * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
-    const size_t b_hv = (size_t)n * 2 * k * 4, b_hi = (size_t)n * 2 * k * 8, b_sub = (size_t)n * dc * 4;
+    // (heap rows in global memory: only the thread-per-query replay of kernels.hip beyond its LDS sizes needs them)
+    const bool heap_rows = !(k > 128 && vlq::imi_minsum_wide_ok(T, k, kc));
+    const size_t b_hv = heap_rows ? (size_t)n * 2 * k * 4 : 0, b_hi = heap_rows ? (size_t)n * 2 * k * 8 : 0, b_sub = (size_t)n * dc * 4;
     TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + 2 * b_sub + 256));
     char* p = h->ws_imi.as<char>();
     float* tab[2] = {(float*)p, (float*)(p + b_tab)};
@@ -399,6 +401,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
                                          argmin ? nullptr : tab[m], n, kc, dc, h->stream, tmin, argmin ? 0 : n_pad);
         }
         if (argmin) vlq::launch_coarse_argmin(tmin, n, kc, sv[m], si[m], h->stream);
+        else if (T > 1024) vlq::launch_row_select_sorted(tab[m], n, kc, kc, T, sv[m], si[m], h->stream);   // (imi_wide.hip; checked by the caller)
         else vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
     }
     vlq::launch_imi_minsum(sv[0], si[0], sv[1], si[1], T, n, k, kc, h->imi_nbits, hv, hi, cdis_dev, keys_dev,
@@ -746,10 +749,11 @@ int check_search_args(vlq_ivfpq_t h, int64_t n, const void* x, int nprobe, int k
                       const void* I) {
     if (n < 0) return fail(VLQ_ERR_INVALID, "n < 0");
     if (n > 0 && (!x || !D || !I)) return fail(VLQ_ERR_INVALID, "null buffer");
-    if (nprobe < 1 || nprobe > VLQ_MAX_NPROBE)
-        return fail(VLQ_ERR_INVALID, "nprobe=%d outside 1..%d", nprobe, VLQ_MAX_NPROBE);
+    // (a multi-index quantizer's coarse stage goes on to VLQ_MAX_IMI_NPROBE cells: imi_wide.hip)
+    const int max_probe = (h && h->imi_nbits > 0) ? VLQ_MAX_IMI_NPROBE : VLQ_MAX_NPROBE;
+    if (nprobe < 1 || nprobe > max_probe)
+        return fail(VLQ_ERR_INVALID, "nprobe=%d outside 1..%d", nprobe, max_probe);
     if (k < 1 || k > VLQ_MAX_K) return fail(VLQ_ERR_INVALID, "k=%d outside 1..%d", k, VLQ_MAX_K);
-    (void)h;
     return VLQ_OK;
 }
 
@@ -852,7 +856,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_own_recs, &h->ws_own_seg, &h->ws_own_items, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent, &h->ws_Dr, &h->ws_Ir,
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent, &h->ws_Dr, &h->ws_Ir, &h->ws_keys_run, &h->ws_cdis_run,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi,
                       // the float16 screen of the coarse stage: built for every index at set_coarse_centroids
                       &h->screen.half, &h->screen.mu, &h->screen.norm_c, &h->imi_screen[0].half, &h->imi_screen[0].mu,
@@ -1213,6 +1217,42 @@ int vlq_ivfpq_coarse_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe
                           (size_t)n * nprobe * 8);
 }
 
+// More probes than one scan launch takes (the CPU class has no limit: tests/sift1b_imi_pq.cpp asks for 2048): the probe list
+// is cut into runs of <= 1024 in coarse order (strided device copies), every run is scanned, and the rows are joined by
+// (distance, run, place in the run's row) -- the (distance, scan position) order of one long scan (merge_topk_kernel: ties go
+// to the lower part, then the lower rank).  Pages of 32 768 queries bound the run buffers.
+static int scan_runs_dev(vlq_ivfpq_t h, int64_t n, const float* xd, const int64_t* kd, const float* cd, int nprobe, int k, float* Dd,
+                         int64_t* Id, int store_pairs) {
+    if (nprobe <= VLQ_MAX_NPROBE) return scan_dev(h, n, xd, kd, cd, nprobe, k, Dd, Id, store_pairs);
+    if (h->max_codes != 0)
+        return fail(VLQ_ERR_UNSUPPORTED, "max_codes=%lld with nprobe=%d > %d: the limit would apply to every run of probes, not to the "
+                    "whole list (IndexIVFPQ.cpp:1052)", (long long)h->max_codes, nprobe, VLQ_MAX_NPROBE);
+    const int nruns = (nprobe + VLQ_MAX_NPROBE - 1) / VLQ_MAX_NPROBE;
+    const int64_t page = 32768;
+    const int64_t np = std::min(n, page);
+    TRY(h->ws_keys_run.reserve((size_t)np * VLQ_MAX_NPROBE * 8));
+    TRY(h->ws_cdis_run.reserve((size_t)np * VLQ_MAX_NPROBE * 4));
+    TRY(h->ws_Dr.reserve((size_t)nruns * np * k * 4));
+    TRY(h->ws_Ir.reserve((size_t)nruns * np * k * 8));
+    const uint64_t nq0 = h->stat_nq;
+    for (int64_t i0 = 0; i0 < n; i0 += page) {
+        const int64_t ni = std::min(page, n - i0);
+        for (int r = 0; r < nruns; r++) {
+            const int p0 = r * VLQ_MAX_NPROBE, pn = std::min(VLQ_MAX_NPROBE, nprobe - p0);
+            HIP_TRY(hipMemcpy2DAsync(h->ws_keys_run.p, (size_t)pn * 8, kd + i0 * nprobe + p0, (size_t)nprobe * 8, (size_t)pn * 8, (size_t)ni,
+                                     hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpy2DAsync(h->ws_cdis_run.p, (size_t)pn * 4, cd + i0 * nprobe + p0, (size_t)nprobe * 4, (size_t)pn * 4, (size_t)ni,
+                                     hipMemcpyDeviceToDevice, h->stream));
+            TRY(scan_dev(h, ni, xd + i0 * h->d, h->ws_keys_run.as<int64_t>(), h->ws_cdis_run.as<float>(), pn, k,
+                         h->ws_Dr.as<float>() + (size_t)r * ni * k, h->ws_Ir.as<int64_t>() + (size_t)r * ni * k, store_pairs));
+        }
+        vlq::launch_merge_topk(h->ws_Dr.as<float>(), h->ws_Ir.as<int64_t>(), ni, k, nruns, Dd + i0 * k, Id + i0 * k, h->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    h->stat_nq = nq0 + (uint64_t)n;          // (the reference counts a query once, however its probes were cut)
+    return VLQ_OK;
+}
+
 int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const int64_t* keys,
                                  const float* coarse_dis, int nprobe, int k, float* D, int64_t* I,
                                  int store_pairs) {
@@ -1231,30 +1271,7 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
     bool copyD, copyI;
     TRY(stage_out(D, (size_t)n * k * 4, h->ws_D, &Dd, &copyD));
     TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI));
-    if (nprobe <= VLQ_MAX_NPROBE) {
-        TRY(scan_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k,
-                     (float*)Dd, (int64_t*)Id, store_pairs));
-    } else {
-        // The probe list is cut into runs of <= 1024 in coarse order (strided device copies of the staged arrays), every run is
-        // scanned, and the rows are joined by (distance, run, place in the run's row) -- the (distance, scan position) order
-        // of one long scan (merge_topk_kernel: ties go to the lower part, then the lower rank).
-        const int nruns = (nprobe + VLQ_MAX_NPROBE - 1) / VLQ_MAX_NPROBE;
-        TRY(h->ws_keys.reserve((size_t)n * VLQ_MAX_NPROBE * 8));
-        TRY(h->ws_cdis.reserve((size_t)n * VLQ_MAX_NPROBE * 4));
-        TRY(h->ws_Dr.reserve((size_t)nruns * n * k * 4));
-        TRY(h->ws_Ir.reserve((size_t)nruns * n * k * 8));
-        for (int r = 0; r < nruns; r++) {
-            const int p0 = r * VLQ_MAX_NPROBE, pn = std::min(VLQ_MAX_NPROBE, nprobe - p0);
-            HIP_TRY(hipMemcpy2DAsync(h->ws_keys.p, (size_t)pn * 8, (const int64_t*)kd + p0, (size_t)nprobe * 8, (size_t)pn * 8, (size_t)n,
-                                     hipMemcpyDeviceToDevice, h->stream));
-            HIP_TRY(hipMemcpy2DAsync(h->ws_cdis.p, (size_t)pn * 4, (const float*)cd + p0, (size_t)nprobe * 4, (size_t)pn * 4, (size_t)n,
-                                     hipMemcpyDeviceToDevice, h->stream));
-            TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), pn, k,
-                         h->ws_Dr.as<float>() + (size_t)r * n * k, h->ws_Ir.as<int64_t>() + (size_t)r * n * k, store_pairs));
-        }
-        vlq::launch_merge_topk(h->ws_Dr.as<float>(), h->ws_Ir.as<int64_t>(), n, k, nruns, (float*)Dd, (int64_t*)Id, h->stream);
-        HIP_TRY(hipGetLastError());
-    }
+    TRY(scan_runs_dev(h, n, (const float*)xd, (const int64_t*)kd, (const float*)cd, nprobe, k, (float*)Dd, (int64_t*)Id, store_pairs));
     TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
     // host outputs: the call has synchronised, so an invalid key is reported here and now; device
     // outputs: the call stays asynchronous and the flag surfaces at the next vlq_ivfpq_stats()
@@ -1294,8 +1311,8 @@ int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k
     TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     // IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081): quantizer->search, then search_knn_with_key
     TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
-    TRY(scan_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
-                 (float*)Dd, (int64_t*)Id, 0));
+    TRY(scan_runs_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
+                      (float*)Dd, (int64_t*)Id, 0));
     TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));
     if ((zcD || zcI) && !(copyD || copyI)) HIP_TRY(hipStreamSynchronize(h->stream));    // rows in the caller's memory on return
     return VLQ_OK;

@@ -143,6 +143,7 @@ struct vlq_ivfpq_s {
     // workspace
     DevBuf ws_Dp, ws_Ip;          // partial top-k rows of the split scan (small batches)
     DevBuf ws_Dr, ws_Ir;          // rows of the runs of a search with more than VLQ_MAX_NPROBE probes
+    DevBuf ws_keys_run, ws_cdis_run;   // ... and one run's keys / coarse distances (ws_keys / ws_cdis hold the whole probe list)
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
         ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin, walk_state;
     int64_t walk_key = -1;       // (nprobe, k, batch class) the walk times in walk_state were measured for

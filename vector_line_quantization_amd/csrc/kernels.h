@@ -225,6 +225,14 @@ void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, c
                        int64_t nq, int k, int kc, int imi_nbits, float* heap_val, int64_t* heap_id,
                        float* sums, int64_t* keys, hipStream_t s);
 
+// imi_wide.hip: the T <= 4096 smallest entries of every row in (value, column) order (ncol % 4 == 0; ld = row stride),
+// and the MinSumK replay for 64 < k <= 4096 by one wave per query with its heap in LDS
+bool row_select_sorted_ok(int ncol, int T);
+void launch_row_select_sorted(const float* dist, int64_t nq, int64_t ld, int ncol, int T, float* sv, int64_t* si, hipStream_t s);
+bool imi_minsum_wide_ok(int T, int k, int kc);
+void launch_imi_minsum_wide(const float* sv0, const int64_t* si0, const float* sv1, const int64_t* si1, int T, int64_t nq, int k,
+                            int kc, int imi_nbits, float* sums, int64_t* keys, hipStream_t s);
+
 // out[m][c][j] = in[m][j][c]
 void launch_transpose_pq(const float* in, int M, int ksub, int dsub, float* out, hipStream_t s);
 

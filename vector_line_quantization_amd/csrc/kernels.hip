@@ -1728,6 +1728,12 @@ void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, c
                            sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums, keys);
         return;
     }
+    // beyond 128 cells the thread-per-query kernel's 32 heaps no longer fit a workgroup's LDS: one wave per query (imi_wide.hip)
+    static const int wide_from = getenv("VLQ_IMI_MINSUM_WIDE_FROM") ? atoi(getenv("VLQ_IMI_MINSUM_WIDE_FROM")) : 129;
+    if (k >= wide_from && imi_minsum_wide_ok(T, k, kc)) {
+        launch_imi_minsum_wide(sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums, keys, s);
+        return;
+    }
     constexpr int NTH = 32;
     const size_t smem = (size_t)NTH * ((size_t)4 * k * 4 + (size_t)4 * T * 4);
     if (k > 1 && smem <= 128 * 1024 && kc <= 32768 && T <= 32768) {
