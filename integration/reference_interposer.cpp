@@ -3,6 +3,10 @@
 // This file is the binding a maintainer of the reference adds.  It is compiled against the REFERENCE's
 // headers (-I/root/reference: class layouts of faiss::IndexIVFPQ / IndexFlat / MultiIndexQuantizer) into
 // libvlq_interpose.so and defines, with the reference's own signatures (IndexIVFPQ.h:56-59,140-149),
+//     faiss::IndexIVFPQ::search                (IndexIVFPQ.cpp:1063-1081) -> vlq_ivfpq_search (coarse stage + scan on the device:
+//                                                                            the probe lists never visit the host)
+//     faiss::MultiIndexQuantizer::search       (IndexPQ.cpp:804-857), k > 1 -> vlq_ivfpq_coarse_search of the handle that holds its
+//                                                                            sub-centroids (callers other than IndexIVFPQ::search)
 //     faiss::IndexIVFPQ::search_knn_with_key   (IndexIVFPQ.cpp:964-1060)  -> vlq_ivfpq_search_preassigned
 //     faiss::IndexIVFPQ::add_core_o            (IndexIVFPQ.cpp:192-272)   -> vlq_ivfpq_encode_preassigned + host append
 //     faiss::IndexIVFPQ::precompute_table      (IndexIVFPQ.cpp:392-459)   -> vlq_ivfpq_get_precomputed_table
@@ -28,11 +32,13 @@
 #include <fcntl.h>
 #include <stdarg.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <typeinfo>
 #include <unordered_map>
 #include <vector>
 
@@ -55,15 +61,22 @@ struct State {
     // loops, autotune) must not inherit a handle of another shape
     int d = 0, M = 0, nbits = 0;
     size_t nlist = 0;
+    const faiss::MultiIndexQuantizer* miq = nullptr;   // the multi-index quantizer whose sub-centroids the handle holds ...
+    uint64_t miq_sig = 0;                              // ... and their signature
 };
 
 std::mutex mu;
 std::unordered_map<const faiss::IndexIVFPQ*, State> states;
+// a multi-index quantizer -> the state of the index it was last synchronised under (its handle holds the sub-centroids; the index
+// object itself is never dereferenced through this map)
+std::unordered_map<const faiss::MultiIndexQuantizer*, State*> by_quantizer;
 
 struct Counters {
     unsigned long long searches = 0, queries = 0, ncode = 0, adds = 0, vectors = 0, tables = 0, fallbacks = 0, uploads = 0;
+    unsigned long long whole = 0, coarse = 0;   // IndexIVFPQ::search calls served whole; MultiIndexQuantizer::search calls served
     double knn_seconds = 0;        // wall time inside search_knn_with_key, device path or the reference's own definition alike
-    double miq_seconds = 0;        // ... and inside the reference's MultiIndexQuantizer::search (never replaced)
+    double miq_seconds = 0;        // ... inside MultiIndexQuantizer::search with k > 1, the reference's own code or the device
+    double search_seconds = 0;     // ... and inside IndexIVFPQ::search served whole by the device (coarse stage + scan + copies)
 } cnt;
 
 double now_s() {
@@ -80,12 +93,15 @@ void check(int rc, const char* what) {
 }
 
 void report() {
+    by_quantizer.clear();
     for (auto& kv : states)            // the handles' device memory goes back before the process ends
         if (kv.second.h) { vlq_ivfpq_destroy(kv.second.h); kv.second.h = nullptr; }
     fprintf(stderr,
             "[vlq-interpose] device searches=%llu queries=%llu ncode=%llu adds=%llu vectors=%llu tables=%llu "
-            "list_uploads=%llu cpu_fallbacks=%llu knn_with_key_seconds=%.6f multi_index_search_seconds=%.6f\n",
-            cnt.searches, cnt.queries, cnt.ncode, cnt.adds, cnt.vectors, cnt.tables, cnt.uploads, cnt.fallbacks, cnt.knn_seconds, cnt.miq_seconds);
+            "list_uploads=%llu cpu_fallbacks=%llu knn_with_key_seconds=%.6f multi_index_search_seconds=%.6f "
+            "whole_searches=%llu whole_search_seconds=%.6f device_coarse_searches=%llu\n",
+            cnt.searches, cnt.queries, cnt.ncode, cnt.adds, cnt.vectors, cnt.tables, cnt.uploads, cnt.fallbacks, cnt.knn_seconds, cnt.miq_seconds,
+            cnt.whole, cnt.search_seconds, cnt.coarse);
 }
 
 struct AtExit { AtExit() { atexit(report); } } at_exit_registration;
@@ -124,6 +140,7 @@ State& sync(const faiss::IndexIVFPQ* ix, bool with_lists) {
     State& st = states[ix];
     if (st.h && (st.d != ix->d || st.nlist != ix->nlist || st.M != (int)ix->pq.M || st.nbits != (int)ix->pq.nbits)) {
         vlq_ivfpq_destroy(st.h);       // another index lives at this address now
+        if (st.miq) by_quantizer.erase(st.miq);
         st = State();
     }
     if (!st.h) {
@@ -144,6 +161,12 @@ State& sync(const faiss::IndexIVFPQ* ix, bool with_lists) {
         else check(vlq_ivfpq_set_imi_centroids(st.h, (int)mi->pq.nbits, mi->pq.centroids.data()), "vlq_ivfpq_set_imi_centroids");
         check(vlq_ivfpq_set_pq_centroids(st.h, ix->pq.centroids.data()), "vlq_ivfpq_set_pq_centroids");
         st.cent_sig = s;
+        if (st.miq) by_quantizer.erase(st.miq);
+        st.miq = mi;
+        if (mi) {
+            st.miq_sig = sig_floats(mix(3, mi->pq.nbits), mi->pq.centroids.data(), mi->pq.centroids.size());
+            by_quantizer[mi] = &st;
+        }
     }
     check(vlq_ivfpq_set_search_options(st.h, ix->by_residual ? 1 : 0,
                                        ix->by_residual ? (ix->use_precomputed_table ? 1 : 0) : 0, (int64_t)ix->max_codes),
@@ -268,12 +291,65 @@ void IndexIVFPQ::add_core_o(idx_t n, const float* x, const long* xids, float* re
     cnt.vectors += n;
 }
 
-// timing only: the coarse quantizer of the multi-index drivers runs in the reference's own code in both runs; its wall time is
-// printed beside the interposed search's so that a driver's own "query time" can be read (VLQ_INTERPOSE_TIMING=1)
+// IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081: quantizer->search, then search_knn_with_key) served whole: the coarse stage runs
+// on the device too and the probe lists (n x nprobe keys and distances: 246 MB for 10 000 queries at the multi-index drivers'
+// nprobe = 2048) stay in HBM.  A flat quantizer's coarse distances are the reference's to rounding (its sgemm's order is the BLAS
+// vendor's: SURVEY.md 8c); a multi-index quantizer's cells are MinSumK's, replayed (csrc/imi_wide.hip).  VLQ_INTERPOSE_SEARCH=0
+// keeps the reference's own body (its quantizer->search, then the interposed search_knn_with_key).
+void IndexIVFPQ::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    static const bool whole_off = getenv("VLQ_INTERPOSE_SEARCH") && strcmp(getenv("VLQ_INTERPOSE_SEARCH"), "0") == 0;
+    const MultiIndexQuantizer* mi = device_shape(this) ? imi2(this) : nullptr;
+    const IndexFlat* fl = device_shape(this) ? flat_l2(this) : nullptr;
+    // (the quantizer's own search() must be the one replaced: a subclass may override it)
+    const bool plain_quantizer = quantizer && ((mi && typeid(*quantizer) == typeid(MultiIndexQuantizer)) ||
+                                               (fl && (typeid(*quantizer) == typeid(IndexFlatL2) || typeid(*quantizer) == typeid(IndexFlat))));
+    const bool on_device = !whole_off && plain_quantizer && polysemous_ht == 0 && scan_table_threshold == 0 && k >= 1 && k <= VLQ_MAX_K &&
+                           nprobe >= 1 && (mi ? (nprobe <= VLQ_MAX_IMI_NPROBE && (nprobe <= VLQ_MAX_NPROBE || max_codes == 0)) : nprobe <= VLQ_MAX_NPROBE) &&
+                           nprobe <= nlist && !(mi && by_residual && use_precomputed_table == 0);
+    if (!on_device) {
+        typedef void (*fn_t)(const IndexIVFPQ*, idx_t, const float*, idx_t, float*, idx_t*);
+        static fn_t ref = next_definition<fn_t>("_ZNK5faiss10IndexIVFPQ6searchElPKflPfPl");
+        ref(this, n, x, k, distances, labels);         // (its search_knn_with_key is the interposed one above)
+        return;
+    }
+    if (n == 0) return;
+    const double t0 = now_s();
+    std::lock_guard<std::mutex> lock(mu);
+    State& st = sync(this, true);
+    static_assert(sizeof(long) == sizeof(int64_t), "idx_t is 64 bits");
+    check(vlq_ivfpq_search(st.h, (int64_t)n, x, (int)nprobe, (int)k, distances, (int64_t*)labels), "vlq_ivfpq_search");
+    uint64_t nq = 0, ncode = 0;
+    check(vlq_ivfpq_stats(st.h, &nq, &ncode, 1), "vlq_ivfpq_stats");
+    indexIVFPQ_stats.nq += n;
+    indexIVFPQ_stats.ncode += ncode;
+    cnt.searches++;
+    cnt.whole++;
+    cnt.queries += n;
+    cnt.ncode += ncode;
+    cnt.search_seconds += now_s() - t0;
+}
+
+// MultiIndexQuantizer::search (IndexPQ.cpp:804-857) for callers other than IndexIVFPQ::search above (IndexIVFPQR::search, a
+// program of its own): k > 1 goes to the coarse stage of the handle that holds this quantizer's sub-centroids -- the one of the
+// IndexIVFPQ it was last synchronised under -- when there is one and the sub-centroids are still those; k = 1 (the assignment of
+// add) and everything else runs the reference's own definition.  Wall time of the k > 1 calls is reported either way.
 void MultiIndexQuantizer::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    static const bool off = getenv("VLQ_INTERPOSE") && strcmp(getenv("VLQ_INTERPOSE"), "off") == 0;
+    const double t0 = now_s();
+    if (!off && k > 1 && k <= VLQ_MAX_IMI_NPROBE && n > 0 && pq.M == 2) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = by_quantizer.find(this);
+        if (it != by_quantizer.end() && it->second->h &&
+            it->second->miq_sig == sig_floats(mix(3, pq.nbits), pq.centroids.data(), pq.centroids.size()) &&
+            (idx_t)k <= ntotal) {
+            check(vlq_ivfpq_coarse_search(it->second->h, (int64_t)n, x, (int)k, distances, (int64_t*)labels), "vlq_ivfpq_coarse_search");
+            cnt.coarse++;
+            cnt.miq_seconds += now_s() - t0;
+            return;
+        }
+    }
     typedef void (*fn_t)(const MultiIndexQuantizer*, idx_t, const float*, idx_t, float*, idx_t*);
     static fn_t ref = next_definition<fn_t>("_ZNK5faiss19MultiIndexQuantizer6searchElPKflPfPl");
-    const double t0 = now_s();
     ref(this, n, x, k, distances, labels);
     if (k > 1) cnt.miq_seconds += now_s() - t0;        // (k = 1: the assignment of add)
 }
@@ -298,7 +374,8 @@ void IndexIVFPQ::precompute_table() {
     precomputed_table.resize((miq ? miq->pq.ksub : nlist) * pq.M * pq.ksub);
     check(vlq_ivfpq_get_precomputed_table(st.h, precomputed_table.data()), "vlq_ivfpq_get_precomputed_table");
     cnt.tables++;
-    if (ntotal > 0 && !st.warmed) {
+    static const bool warm_off = getenv("VLQ_INTERPOSE_WARMUP") && strcmp(getenv("VLQ_INTERPOSE_WARMUP"), "0") == 0;
+    if (ntotal > 0 && !st.warmed && !warm_off) {
         // one throw-away search per handle (every probe key -1: nothing is scanned): the runtime loads a code object at the
         // first launch from it and the library grows its workspace at the first call -- one-time costs of ~0.1 s that do not
         // belong inside the one search call a driver times
@@ -309,6 +386,9 @@ void IndexIVFPQ::precompute_table() {
         for (int wkk : {10, 128})
             check(vlq_ivfpq_search_preassigned(st.h, (int64_t)wn, wx.data(), wk.data(), wc.data(), (int)wp, wkk, wD.data(), wI.data(), 0),
                   "vlq_ivfpq_search_preassigned (warm-up)");
+        // ... and of a whole search at the multi-index drivers' probe count (coarse kernels of csrc/imi_wide.hip and their workspace)
+        if (miq)
+            check(vlq_ivfpq_search(st.h, (int64_t)wn, wx.data(), (int)std::min<size_t>(2048, nlist), 128, wD.data(), wI.data()), "vlq_ivfpq_search (warm-up)");
         uint64_t q_ = 0, c_ = 0;
         check(vlq_ivfpq_stats(st.h, &q_, &c_, 1), "vlq_ivfpq_stats");
         st.warmed = true;

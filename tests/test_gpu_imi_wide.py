@@ -60,7 +60,7 @@ def test_wide_coarse_stage_equals_the_oracle(nbits, dc, grid, nq, probes):
 
 
 def test_limits():
-    g, ox, xq = _pair(6, 8, 1000, 4, 5)
+    g, ox, xq = _pair(6, 8, 1000, 16, 5)
     with pytest.raises(Exception):
         g.coarse_search(xq, 4097)            # VLQ_MAX_IMI_NPROBE + 1
     g.close()

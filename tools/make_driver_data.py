@@ -7,7 +7,7 @@ truth by brute force.  The drivers' hard-coded /home/data prefix is redirected t
                       python tools/make_driver_data.py <root> sift1b <cwd> [nb nq]
                       python tools/make_driver_data.py <root> deep1b <cwd> [nb nq]   (tests/deep1b_imi_pq.cpp, deep1b16_imi_pq.cpp)
                       ... [nb nq populated]: also the drivers' POPULATED cache (sift1b: 1; deep1b: 8 or 16 = the code size), so that
-                      a test needs no populating run
+                      a test needs no populating run; deep1b -8 / -16: only that driver's trained cache (it populates itself)
 The second form prepares tests/sift1b_imi_pq.cpp: byte-valued base.umem / query.umem / learn.umem ("num dim" text
 header, data from byte 20, :100-150), gnd/idx_1000M.ivecs, and -- in <cwd>, where the driver looks for its cache
 (:225-243) -- sift1b_14_8_trained_index.faissindex in the reference's file format (index_io.cpp:226-317): the
@@ -231,9 +231,9 @@ def deep1b(root, cwd, nb=500000, nq=1000, populated=0):
     for M in (8, 16):
         ds = d // M
         pq = np.stack([res[r.permutation(20000)[:256], m * ds:(m + 1) * ds] for m in range(M)]).astype(np.float32)
-        if populated and populated != M:
-            continue               # (populated = 8 / 16: only that driver's files)
-        if populated:
+        if populated and abs(populated) != M:
+            continue               # (populated = 8 / 16: only that driver's files; -8 / -16: only that driver's TRAINED cache)
+        if populated > 0:
             write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_trained_index.faissindex" % M), d, 1, imi[:, :2], M, pq)
             write_imi_ivfpq_index(os.path.join(cwd, "deep1b_14_%d_populated_index.faissindex" % M), d, nbits, imi, M, pq,
                                   lists=populated_lists(xb, imi, pq, nbits, M))

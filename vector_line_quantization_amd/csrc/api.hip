@@ -282,7 +282,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     const int64_t n_pad = (n + 127) / 128 * 128;
     const size_t b_tab = (size_t)n_pad * kc * 4, b_sv = (size_t)n * T * 4, b_si = (size_t)n * T * 8;
     // (heap rows in global memory: only the thread-per-query replay of kernels.hip beyond its LDS sizes needs them)
-    const bool heap_rows = !(k > 128 && vlq::imi_minsum_wide_ok(T, k, kc));
+    const bool heap_rows = !(k <= 64 || vlq::imi_minsum_wide_ok(T, k, kc)) || getenv("VLQ_IMI_MINSUM_WIDE_FROM") || getenv("VLQ_IMI_MINSUM_LDS");
     const size_t b_hv = heap_rows ? (size_t)n * 2 * k * 4 : 0, b_hi = heap_rows ? (size_t)n * 2 * k * 8 : 0, b_sub = (size_t)n * dc * 4;
     TRY(h->ws_imi.reserve(2 * b_tab + 2 * b_sv + 2 * b_si + b_hv + b_hi + 2 * b_sub + 256));
     char* p = h->ws_imi.as<char>();

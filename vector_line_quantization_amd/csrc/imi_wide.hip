@@ -9,16 +9,24 @@
 //                              stopping as soon as the boundary bin is taken whole (two passes on real data), wave-aggregated
 //                              compaction, one bitonic sort of the T 64-bit (value, column) keys in LDS.  The running
 //                              wave selection of kernels.hip (WaveSelect<16>) stops at 1024.
-//   imi_minsum_wide_kernel     the MinSumK replay (IndexPQ.cpp:690-778) for 64 < k <= 4096: one wave per query, its
-//                              binary heap ({sum : term}, 8 bytes an entry) and the two sorted tables in LDS, lane 0 walks.
-//                              The walk is a chain of dependent LDS round trips, so a sift-down reads a node's children
-//                              AND grandchildren in one trip (two heap levels per round trip); the heap never holds more
-//                              than k entries (two after the first cell, one more per emitted cell, the last cell's
-//                              pushes feed nothing and are skipped), so k = T = 2048 is 32 KB: five queries per CU.
-//                              Same comparisons on the same heap positions as Heap.h:89-127 with CMin => the same pops in
-//                              the same order, ties and twice-emitted cells included.  (The thread-per-query kernels of
-//                              kernels.hip keep 32 heaps per workgroup in LDS up to k = 128 and fall back to a heap in
-//                              global memory beyond: ~25 dependent memory round trips per emitted cell.)
+//   imi_minsum_wide_kernel     the MinSumK replay (IndexPQ.cpp:690-778) for 64 < k <= 4096: one wave per query, its binary
+//                              heap ({sum : term}, 8 bytes an entry) in LDS.  The heap never holds more than k entries (two
+//                              after the first cell, one more per emitted cell, the last cell's pushes feed nothing and are
+//                              skipped), so k = 2048 is 16 KB: ten queries per CU.  The walk is one chain of dependent steps,
+//                              and a single wave issues an instruction every four cycles at best, so the wave's lanes do a
+//                              sift's comparisons side by side: a sift-down reads five levels of descendants in one LDS
+//                              round trip (62 lanes, one entry each), every pair picks its smaller child at once, the picks
+//                              are followed from the node down by five ballots, and the entries on the path move up in one
+//                              write; a push reads all ancestors of the new slot at once and moves the ones the new value
+//                              beats.  Same comparisons on the same heap positions as Heap.h:89-127 with CMin => the same
+//                              pops in the same order, ties and twice-emitted cells included.  The output holds TERMS during
+//                              the walk and is turned into keys by all 64 lanes behind a barrier; a cell's four table
+//                              entries are fetched by four lanes (vector loads: a scalar load in flight would turn every
+//                              LDS wait into a wait for memory) before the sift-down and used after it.  Measured, 10 000
+//                              queries, 2 x 14 bits, k = 2048: lane 0 walking alone with heap and tables in LDS (five
+//                              queries per CU, ~800 scalar instructions per cell) 47 ms; this kernel: see DESIGN.md 3.1.
+//                              (The thread-per-query kernels of kernels.hip keep 32 heaps per workgroup in LDS up to k = 128
+//                              and fall back to a heap in global memory beyond.)
 #include "kernels.h"
 #include "wave_topk.cuh"
 
@@ -190,105 +198,125 @@ void launch_row_select_sorted(const float* dist, int64_t nq, int64_t ld, int nco
 __global__ __launch_bounds__(64) void imi_minsum_wide_kernel(const float* __restrict__ sv0, const int64_t* __restrict__ si0,
                                                              const float* __restrict__ sv1, const int64_t* __restrict__ si1, int T,
                                                              int64_t nq, int k, int kc, int imi_nbits, float* __restrict__ sums,
-                                                             int64_t* __restrict__ keys) {
+                                                             int64_t* keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
     // heap slot i (1-based, Heap.h's indexing) at byte 8 * (i - 1); {sum bits : term}, term = r0 | r1 << 16
     u64* heap = reinterpret_cast<u64*>(smraw) - 1;
-    float* v0 = reinterpret_cast<float*>(smraw + (size_t)8 * k);
-    float* v1 = v0 + T;
-    for (int j = lane; j < T; j += 64) { v0[j] = sv0[q * T + j]; v1[j] = sv1[q * T + j]; }
-    __syncthreads();
-    if (lane != 0) return;
-    const int64_t* x0 = si0 + q * T;
-    const int64_t* x1 = si1 + q * T;
+    const float* t0 = sv0 + q * T;
+    const float* t1 = sv1 + q * T;
     float* out_s = sums + q * k;
     int64_t* out_k = keys + q * k;
     auto fval = [](u64 e) { return __uint_as_float((uint32_t)(e >> 32)); };
     auto entry = [](float v, int id) { return ((u64)__float_as_uint(v) << 32) | (uint32_t)id; };
-    auto push = [&](int n, float val, int id) {         // Heap.h:110-127 with CMin; n = size after the push
-        int i = n;
-        while (i > 1) {
-            const int f = i >> 1;
-            const u64 ef = heap[f];
-            if (!(val < fval(ef))) break;
-            heap[i] = ef;
-            i = f;
-        }
-        heap[i] = entry(val, id);
+    auto rl = [](int x, int l) { return __builtin_amdgcn_readlane(x, l); };
+    // A lane's place in the fan of descendants a sift-down reads at once: lanes 0-1 the children of the current node, 2-5 its
+    // grandchildren, ... 30-61 the fifth level; lane = 2^L - 2 + p, slot = (node << L) + p.  Siblings are lane ^ 1.
+    const int fan_t = lane + 2;
+    const int L = 31 - __clz(fan_t);
+    const int fp = fan_t - (1 << L);
+    const bool fan = L <= 5;
+    const int parent_lane = L >= 2 ? (1 << (L - 1)) - 2 + (fp >> 1) : 0;
+    const bool even = (lane & 1) == 0;
+    u64 top = 0;                                        // heap[1], carried in registers
+
+    // Heap.h:110-127 with CMin; n = size after the push.  Lane j holds the j-th ancestor of the new slot; the new value climbs
+    // past the nearest ancestors it beats (consecutive ones from the slot up), each of which moves one slot down its path.
+    auto push = [&](int n, float val, int id) {
+        const int a = lane < 30 ? (n >> (lane + 1)) : 0;
+        const u64 e = a >= 1 ? heap[a] : 0ull;
+        const u64 climb = __ballot(a >= 1 && val < fval(e));
+        const int c = __builtin_ctzll(~climb);
+        if (lane < c) heap[n >> lane] = e;
+        const int pos = n >> c;
+        const u64 ne = entry(val, id);
+        if (lane == 0) heap[pos] = ne;
+        if (pos == 1) top = ne;
     };
-    auto pop = [&](int n) {                             // Heap.h:89-108; n = size before the pop
+    // Heap.h:89-108; n = size before the pop.  Five levels of descendants in one LDS round trip; every pair picks its smaller
+    // child at once (the reference's rule, incl. `i2 == k + 1`), the picks are followed down from the node while the last entry
+    // does not win, the picked entries on that path move up one level, all in one write.
+    auto pop = [&](int n) {
         const u64 last = heap[n];
         const float val = fval(last);
         int i = 1;
-        while (true) {
-            const int i1 = i << 1;
-            if (i1 > n) break;
-            // children and grandchildren in one round trip (slots beyond n hold stale entries that are never used)
-            const u64 e1 = heap[i1], e2 = heap[i1 + 1];
-            u64 g[4];
-            const bool deep = 2 * i1 <= n;
-            if (deep) { g[0] = heap[2 * i1]; g[1] = heap[2 * i1 + 1]; g[2] = heap[2 * i1 + 2]; g[3] = heap[2 * i1 + 3]; }
-            int c;
-            u64 ec;
-            if (i1 + 1 == n + 1 || fval(e1) < fval(e2)) { c = i1; ec = e1; } else { c = i1 + 1; ec = e2; }
-            if (val < fval(ec)) break;
-            heap[i] = ec;
-            i = c;
-            // second level from the registers
-            const int j1 = i << 1;
-            if (j1 > n) break;
-            const u64 f1 = (c == i1) ? g[0] : g[2], f2 = (c == i1) ? g[1] : g[3];
-            int c2;
-            u64 ec2;
-            if (j1 + 1 == n + 1 || fval(f1) < fval(f2)) { c2 = j1; ec2 = f1; } else { c2 = j1 + 1; ec2 = f2; }
-            if (val < fval(ec2)) break;
-            heap[i] = ec2;
-            i = c2;
+        while (2 * i <= n) {
+            const int slot = (i << L) + fp;
+            const bool valid = fan && slot <= n;
+            const u64 e = valid ? heap[slot] : 0ull;
+            const float v = fval(e);
+            const float vs = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+            // first child of the pair picked: its sibling is slot n + 1, or it is the smaller one
+            const bool first = even ? (slot + 1 > n || v < vs) : (slot > n || vs < v);
+            const bool chosen = valid && (even == first);
+            u64 on = 0;
+#pragma unroll
+            for (int l = 1; l <= 5; l++) {
+                const bool par_on = l == 1 || ((on >> parent_lane) & 1ull);
+                on |= __ballot(L == l && chosen && par_on);
+            }
+            const u64 stop = __ballot(val < v) & on;
+            const u64 mv = stop ? (on & ((stop & (0ull - stop)) - 1ull)) : on;
+            if ((mv >> lane) & 1ull) heap[slot >> 1] = e;
+            if (mv == 0) break;
+            i = rl(slot, 63 - (int)__builtin_clzll(mv));
+            if (stop || __builtin_popcountll(mv) < 5) break;
         }
-        heap[i] = last;
+        if (lane == 0) heap[i] = last;
     };
     int hs = 0;
-    const float sum0 = __fadd_rn(__fadd_rn(0.f, v0[0]), v1[0]);
-    out_s[0] = sum0;
-    out_k[0] = x0[0] | (x1[0] << imi_nbits);
+    const float sum0 = __fadd_rn(__fadd_rn(0.f, t0[0]), t1[0]);
+    if (lane == 0) { out_s[0] = sum0; out_k[0] = 0; }       // terms now, keys behind the barrier below
     if (T > 1 && k > 1) {
-        push(++hs, __fadd_rn(sum0, __fsub_rn(v0[1], v0[0])), 1);
-        push(++hs, __fadd_rn(sum0, __fsub_rn(v1[1], v1[0])), 1 << 16);
+        push(++hs, __fadd_rn(sum0, __fsub_rn(t0[1], t0[0])), 1);
+        push(++hs, __fadd_rn(sum0, __fsub_rn(t1[1], t1[0])), 1 << 16);
     }
     int kk = 1;
     for (; kk < k; kk++) {
         if (hs == 0) break;
-        const u64 top = heap[1];
         const float s2 = fval(top);
         const int ti = (int)(uint32_t)top;
         const int r0 = ti & 0xffff, r1 = ti >> 16;
-        // everything the iteration will need, requested before the sift-down's chain of round trips
-        const int64_t k0 = x0[r0], k1 = x1[r1];
         const bool p0 = r0 + 1 < kc && r0 + 1 < T, p1 = r1 + 1 < kc && r1 + 1 < T;
-        const float a0 = v0[r0], a1 = v0[p0 ? r0 + 1 : r0], b0 = v1[r1], b1 = v1[p1 ? r1 + 1 : r1];
-        do { pop(hs--); } while (hs > 0 && (int)(uint32_t)heap[1] == ti);
+        // the four table entries of this cell's followers: lanes 0-3, requested before the sift-down's round trips
+        // (loaded and consumed in every iteration, the stores behind the load: the wait in front of the pushes is then a
+        // counted one and the loop head needs none)
+        const int tr = (lane & 2) ? r1 : r0;
+        const int ti_ = tr + (((lane & 1) && ((lane & 2) ? p1 : p0)) ? 1 : 0);
+        const float tv = ((lane & 2) ? t1 : t0)[(lane & 3) == lane ? ti_ : 0];
+        if (lane == 0) { out_s[kk] = s2; out_k[kk] = ti; }
+        do {
+            pop(hs--);
+            top = heap[1];
+        } while (hs > 0 && (int)(uint32_t)top == ti);
+        const int tvb = (int)__float_as_uint(tv);
+        const float a0 = __uint_as_float((uint32_t)rl(tvb, 0)), a1 = __uint_as_float((uint32_t)rl(tvb, 1));
+        const float b0 = __uint_as_float((uint32_t)rl(tvb, 2)), b1 = __uint_as_float((uint32_t)rl(tvb, 3));
         if (kk < k - 1) {                               // (the last cell's pushes would feed nothing)
             if (p0) push(++hs, __fadd_rn(s2, __fsub_rn(a1, a0)), ti + 1);
             if (p1) push(++hs, __fadd_rn(s2, __fsub_rn(b1, b0)), ti + (1 << 16));
         }
-        out_s[kk] = s2;
-        out_k[kk] = k0 | (k1 << imi_nbits);
     }
-    for (; kk < k; kk++) { out_s[kk] = 3.402823466e+38f; out_k[kk] = -1; }       // fewer than k cells
+    if (lane == 0)
+        for (; kk < k; kk++) { out_s[kk] = 3.402823466e+38f; out_k[kk] = -1; }       // fewer than k cells
+    __syncthreads();        // lane 0's terms are visible to the wave: ranks -> sub-quantizer indices, 64 cells at a time
+    const int64_t* x0 = si0 + q * T;
+    const int64_t* x1 = si1 + q * T;
+    for (int j = lane; j < k; j += 64) {
+        const int64_t t = out_k[j];
+        if (t >= 0) out_k[j] = x0[t & 0xffff] | (x1[t >> 16] << imi_nbits);
+    }
 }
 
 bool imi_minsum_wide_ok(int T, int k, int kc) {
-    return k > 1 && k <= 4096 && T <= 4096 && kc <= 32768 && (size_t)8 * k + (size_t)8 * T + 64 <= 160 * 1024;
+    return k > 1 && k <= 4096 && T <= 4096 && kc <= 32768;
 }
 
 void launch_imi_minsum_wide(const float* sv0, const int64_t* si0, const float* sv1, const int64_t* si1, int T, int64_t nq, int k,
                             int kc, int imi_nbits, float* sums, int64_t* keys, hipStream_t s) {
     if (nq <= 0) return;
-    // (+ 32 bytes: a sift-down may read the slots n + 1 .. n + 3 of a full heap -- stale values that are never used;
-    // behind the heap lie the tables, behind the tables this pad)
-    const size_t smem = (size_t)8 * k + (size_t)8 * T + ((k == 2048 && T == 2048) ? 0 : 32);
+    const size_t smem = (size_t)8 * k;
     ensure_dynamic_lds(reinterpret_cast<const void*>(imi_minsum_wide_kernel), smem);
     hipLaunchKernelGGL(imi_minsum_wide_kernel, dim3((unsigned)nq), dim3(64), smem, s, sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums,
                        keys);

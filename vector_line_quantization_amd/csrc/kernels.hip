@@ -1728,8 +1728,10 @@ void launch_imi_minsum(const float* sv0, const int64_t* si0, const float* sv1, c
                            sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums, keys);
         return;
     }
-    // beyond 128 cells the thread-per-query kernel's 32 heaps no longer fit a workgroup's LDS: one wave per query (imi_wide.hip)
-    static const int wide_from = getenv("VLQ_IMI_MINSUM_WIDE_FROM") ? atoi(getenv("VLQ_IMI_MINSUM_WIDE_FROM")) : 129;
+    // beyond 64 cells: one wave per query with its heap in LDS, the lanes sharing a sift's comparisons (imi_wide.hip; 10 000
+    // queries, 2 x 14 bits, k = 128: 1.09 ms against the thread-per-query kernel's 1.55, whose 32 heaps per workgroup stop
+    // fitting LDS at 128 and then live in global memory -- VLQ_IMI_MINSUM_WIDE_FROM=129 for the A/B)
+    static const int wide_from = getenv("VLQ_IMI_MINSUM_WIDE_FROM") ? atoi(getenv("VLQ_IMI_MINSUM_WIDE_FROM")) : 65;
     if (k >= wide_from && imi_minsum_wide_ok(T, k, kc)) {
         launch_imi_minsum_wide(sv0, si0, sv1, si1, T, nq, k, kc, imi_nbits, sums, keys, s);
         return;
