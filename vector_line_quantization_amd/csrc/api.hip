@@ -658,7 +658,10 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 tq.stop();
             }
             StageTimer tm(h, 2);       // exactly the scan kernel
-            if (h->ntotal < (int64_t)h->nlist * 24) vlq::launch_scan16_short(a, h->stream);   // a few codes per list
+            if (h->ntotal < (int64_t)h->nlist * 24) {       // a few codes per list
+                vlq::launch_scan16_short(a, h->stream);
+                snprintf(h->last_scan, sizeof(h->last_scan), "scan16_short_kernel");
+            }
             else {
                 // fewer workgroups than the chip holds (256 CUs x 4): split every query's probes over
                 // several workgroups and join the partial rows -- serving-size batches

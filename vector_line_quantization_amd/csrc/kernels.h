@@ -134,6 +134,7 @@ struct ScanArgs {
     int* walk_state = nullptr;       // per XCD (16 ints apart): running mean of a workgroup's walk time, kept across launches
     int walk_scale = 1000;           // period = measured walk time x this / 1000
     int walk_limit = 0;              // ... list-id order only while their sum is <= this
+    int short_keep_order = 0;    // scan16_short: walk a query's multi-index cells in coarse order (A/B: VLQ_SHORT_KEEP_ORDER) instead of by halves
     int walk_first = -1;         // walk_order.cuh: < 0 = probes in coarse-distance order, else this many nearest first, the rest by list id
     int grid_per_xcd = 0;        // set by the launcher: workgroups per XCD (xcd_chunk unless the tail is split)
     // list-owned schedule (scan16 only, DESIGN.md "list-owned schedule"): the lists are cut into 8

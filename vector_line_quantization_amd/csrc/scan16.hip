@@ -700,6 +700,21 @@ __global__ __launch_bounds__(256) void scan16_short_kernel(ScanArgs a, int queue
             if (lv) ord[nl + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)p;
             nl += __popcll(mask);
         }
+        // Multi-index cells share their halves: a query's 64 cells come from ~20 x ~20 sub-centroids, and each half's 8 KB of
+        // term2 is what crosses the fabric (profiles/r06_scan16_short_pmc.txt).  The cells are walked in (first half, second
+        // half) order so that the four waves work on cells of one first half at a time and a second half comes back a few
+        // cells later, not a whole walk later.  Scan positions are fixed per probe (pm.cum), so the results do not move.
+        static_assert(sizeof(u64) == 8, "");
+        if (a.imi_nbits > 0 && nl <= 64 && nl > 1 && !a.short_keep_order) {
+            __builtin_amdgcn_wave_barrier();
+            const int p = lane < nl ? ord[lane] : 0;
+            const int64_t key = lane < nl ? (int64_t)pm.pkey[p] : 0;
+            const u64 i0 = (u64)(key & ((int64_t(1) << a.imi_nbits) - 1)), i1 = (u64)(key >> a.imi_nbits);
+            const u64 sk = lane < nl ? ((i0 << 40) | (i1 << 16) | (u64)p) : kMaxKey;
+            const u64 so = wave_sort64(sk, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nl) ord[lane] = (uint16_t)(so & 0xffffu);
+        }
         if (lane == 0) { misc[0] = cut; misc[1] = nl; }
     }
     __syncthreads();
@@ -766,6 +781,8 @@ void launch_scan16_short(const ScanArgs& a_in, hipStream_t s) {
     if (a_in.nq <= 0) return;
     ScanArgs a = a_in;
     a.xcd_chunk = (int)((a.nq + 7) / 8);
+    static const bool keep_order = getenv("VLQ_SHORT_KEEP_ORDER") != nullptr;
+    a.short_keep_order = keep_order ? 1 : 0;
     size_t region = (size_t)4096 * 4;                        // the merge area aliases the table
     const size_t merge = (size_t)4 * a.k * 8;
     if (region < merge) region = merge;
