@@ -447,6 +447,149 @@ def vlq_leg(torch, dev, nb=16000000, nq=2000, reps=5, nsample=64):
     return out
 
 
+def _scan_roofline(kernel, kernel_ms, launches, ncode, code_bytes, note):
+    achieved = ncode * code_bytes / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "kernel_ms": kernel_ms, "launches": launches, "achieved": achieved, "peak": 8000.0,
+            "unit": "GB/s", "frac": achieved / 8000.0, "algorithmic_bytes": ncode * code_bytes, "traffic": None, "note": note}
+
+
+def imi_c3_leg(torch, dev, nb=1000000000, nq=10000, reps=5, nsample=64):
+    """BASELINE configs[2] / SURVEY C3 geometry (tests/sift1b_imi_pq.cpp's quantizer): inverted multi-index 2 x 14 bits =
+    2^28 lists over 128 dimensions, M = 16 x 8 bit, nprobe 64, k 10, one batch of 10 000 queries; the database is built on the
+    device (add: multi-index assignment + residual encoding + append, ~30 s) from 1 B uniform synthetic vectors -- the config's full
+    size.  Half the batch are stored vectors (they must find themselves); a query sample
+    is checked bit for bit against the oracle on the lists it probes, fetched back from the device -- coarse cells included (the
+    device replays MinSumK).  Reported beside the headline, never instead of it."""
+    import vector_line_quantization_amd as vlq
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scale_checks
+    d, nbits, M, nprobe, k = 128, 14, 16, 64, 10
+    nlist = 1 << (2 * nbits)
+    rng = np.random.default_rng(0)
+    g = vlq.GpuIVFPQ(d, nlist, M, 8, device=dev.index or 0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    imi = rng.random((2, 1 << nbits, d // 2), dtype=np.float32)
+    g.set_imi_centroids(nbits, imi)
+    pq = ((rng.random((M, 256, d // M), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    g.set_pq_centroids(pq)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    t0 = time.time()
+    first = None
+    step = 10000000
+    for i in range(0, nb, step):
+        xb = torch.rand((min(step, nb - i), d), device=dev, generator=gen)
+        if first is None:
+            first = xb[:nq].clone()
+        g.add(xb)
+        del xb
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    xq = torch.rand((nq, d), device=dev, generator=gen)
+    xq[:nq // 2] = first[:nq // 2]
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        g.search(xq, nprobe, k, D=D, I=I)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(4 * reps):                          # uninstrumented: the two halves of the coarse stage run on two streams
+        g.search(xq, nprobe, k, D=D, I=I)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / (4 * reps)
+    g.stats(reset=True)
+    g.profile(True)
+    g.profile_read(reset=True)
+    for _ in range(reps):
+        g.search(xq, nprobe, k, D=D, I=I)
+    torch.cuda.synchronize()
+    pr = g.profile_read(reset=True)
+    g.profile(False)
+    _n, ncode = g.stats(reset=True)
+    ncode /= reps
+    s1, sk = scale_checks.self_hit(I.cpu().numpy()[:nq // 2])
+    sample = np.r_[0:nsample // 2, nq // 2:nq // 2 + nsample - nsample // 2]
+    chk = scale_checks.check_ivfpq_sample(g, xq[sample].cpu().numpy(), nprobe, k, pq, imi=imi, imi_nbits=nbits)
+    out = {"workload": "IVFPQ over an inverted multi-index, SURVEY C3 geometry: d=128, 2 x 14 bits = 2^28 lists, M=16x8bit, nprobe=64, k=10, "
+                       "%d queries per batch, %d synthetic vectors added on the device" % (nq, nb),
+           "build_s": build_s, "add_vectors_per_s": nb / build_s,
+           "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
+           "stage_ms": {"coarse": pr["coarse_ms"] / reps, "order": pr["tables_ms"] / reps, "scan": pr["scan_ms"] / reps,
+                        "note": "HIP events on the index's stream (both halves of the coarse stage on one stream while they are on)"},
+           "self_hit_first": s1, "self_hit_in_top_k": sk,
+           "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"],
+           "oracle_sample_coarse_cells_equal": bool(chk["coarse_keys_equal"] and chk["coarse_dis_bits_equal"]),
+           "roofline": _scan_roofline(
+               "scan16_short_kernel<1>", pr["scan_ms"] / max(1, pr["scan_calls"]), pr["scan_calls"], ncode, M,
+               "achieved = scanned codes x 16 B / scan-kernel time (HIP events).  What this kernel moves is not codes but the "
+               "precomputed table: each visited cell's two 8 KB half rows (table type 2, IndexIVFPQ.cpp:645-686), 17 x the code "
+               "bytes at 1 B vectors, read at the fabric's ~6.8 TB/s -- counters and what was tried: profiles/r06_scan16_short_pmc.txt")}
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def deep1b_c4_leg(torch, dev, per_list=4096, nq=10000, reps=3, nsample=64):
+    """BASELINE configs[3] / SURVEY C4 geometry (tests/deep1b_imi_pq.cpp's data shape with the flat quantizer of the config line):
+    2^17 lists over 96 dimensions (6-dimensional sub-vectors), M = 16 x 8 bit, nprobe 128, k 100, one batch of 10 000 queries.
+    The lists are loaded as uniformly random code bytes, `per_list` per list (the byte traffic of a populated index without its
+    device-side build; the full-size 1 B-vector build is profiles/r05_deep1b_shape_verified.txt: 7631 codes per list) -- recall
+    is meaningless here, the oracle check of a query sample on the probed lists, fetched back from the device, is not."""
+    import vector_line_quantization_amd as vlq
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scale_checks
+    d, nlist, M, nprobe, k = 96, 1 << 17, 16, 128, 100
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    cent = torch.rand((nlist, d), generator=gen, device=dev)
+    pq = ((torch.rand((M, 256, d // M), generator=gen, device=dev) - 0.5) * 0.1).contiguous()
+    g = vlq.GpuIVFPQ(d, nlist, M, 8, device=dev.index or 0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.set_coarse_centroids(cent)
+    g.set_pq_centroids(pq)
+    nbig = per_list * nlist
+    codes = torch.empty((nbig, M), dtype=torch.uint8, device=dev)
+    for i in range(0, nbig, 1 << 26):
+        codes[i:i + (1 << 26)] = torch.randint(0, 256, (min(1 << 26, nbig - i), M), dtype=torch.uint8, device=dev, generator=gen)
+    g.set_lists(codes, torch.arange(nbig, dtype=torch.int64, device=dev), torch.arange(nlist + 1, dtype=torch.int64, device=dev) * per_list)
+    del codes
+    pick = torch.randint(0, nlist, (nq,), device=dev, generator=gen)
+    xq = (cent[pick] + 0.02 * torch.randn((nq, d), device=dev, generator=gen)).contiguous()
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    for _ in range(2):
+        g.search(xq, nprobe, k, D=D, I=I)
+    torch.cuda.synchronize()
+    g.stats(reset=True)
+    g.profile(True)
+    g.profile_read(reset=True)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        g.search(xq, nprobe, k, D=D, I=I)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / reps
+    pr = g.profile_read(reset=True)
+    g.profile(False)
+    _n, ncode = g.stats(reset=True)
+    ncode /= reps
+    info = g.last_scan_info()
+    chk = scale_checks.check_ivfpq_sample(g, xq[:nsample].cpu().numpy(), nprobe, k, pq.cpu().numpy(), coarse=cent.cpu().numpy())
+    out = {"workload": "IVFPQ, SURVEY C4 geometry: d=96, nlist=2^17, M=16x8bit (dsub 6), nprobe=128, k=100, %d queries per batch, %d "
+                       "synthetic 16-byte codes, %d per list (reduced from 1 B vectors = 7631 per list)" % (nq, nbig, per_list),
+           "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "ncode_per_query": ncode / nq,
+           "stage_ms": {"coarse": pr["coarse_ms"] / reps, "tables_and_order": pr["tables_ms"] / reps, "scan": pr["scan_ms"] / reps},
+           "scan_info": info,
+           "oracle_sample_bit_exact": bool(chk["ok"]), "oracle_sample_queries": chk["queries"],
+           "roofline": _scan_roofline(
+               info.split(" order=")[0].replace("kernel=", "") if isinstance(info, str) else "scan16_kernel", pr["scan_ms"] / max(1, pr["scan_calls"]),
+               pr["scan_calls"], ncode, M,
+               "achieved = scanned codes x 16 B / scan-kernel time (HIP events on the index's stream); lists of %d codes: the kernel "
+               "streams codes, the 16 KB table row per probed list is 1.6 %% of the bytes" % per_list)}
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
 TIMED_PROFILE = 3
 
 
@@ -486,6 +629,8 @@ def main():
                     help="untimed clock pre-warm before the --warmup steps: groups of 16 searches until this much time has passed (at least 64)")
     ap.add_argument("--no-host-buffers", action="store_true")
     ap.add_argument("--no-vlq", action="store_true", help="skip the VLQ (configs[4] / SURVEY C5 geometry) leg")
+    ap.add_argument("--no-imi", action="store_true", help="skip the multi-index (configs[2] / SURVEY C3 geometry) leg")
+    ap.add_argument("--no-deep1b", action="store_true", help="skip the Deep1B-shape (configs[3] / SURVEY C4 geometry) leg")
     ap.add_argument("--cpu-queries", type=int, default=10000)
     args = ap.parse_args()
     defaults = {k: ap.get_default(k) for k in ("nq", "nb", "nt", "d", "nlist", "M", "nprobe", "k", "sigma",
@@ -940,6 +1085,16 @@ def main():
                 out["vlq_c5_geometry"] = vlq_leg(torch, dev)
             except Exception as e:     # noqa: BLE001 -- never lose the headline over the extra leg
                 out["vlq_c5_geometry"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if world == 1 and default_workload and not fdir and not args.no_imi:
+            try:
+                out["imi_c3_geometry"] = imi_c3_leg(torch, dev)
+            except Exception as e:     # noqa: BLE001 -- never lose the headline over an extra leg
+                out["imi_c3_geometry"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if world == 1 and default_workload and not fdir and not args.no_deep1b:
+            try:
+                out["deep1b_c4_geometry"] = deep1b_c4_leg(torch, dev)
+            except Exception as e:     # noqa: BLE001
+                out["deep1b_c4_geometry"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             from oracle import pyoracle, refbench
             try:

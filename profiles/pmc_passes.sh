@@ -14,5 +14,5 @@ i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
   rocprofv3 --pmc $P --kernel-include-regex "vlq::" --output-format csv -d "$OUT/pass$i" -- \
-      python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-buffers --no-vlq "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { tail -5 "$OUT/pass$i.err"; exit 1; }
+      python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-buffers --no-vlq --no-imi --no-deep1b "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" || { tail -5 "$OUT/pass$i.err"; exit 1; }
 done

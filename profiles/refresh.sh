@@ -18,7 +18,7 @@ T="timeout -k 10"
 if [[ $PART == *a* ]]; then
 $T 400 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done" >&2
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline --no-second-dataset --no-host-buffers --no-vlq > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py --no-cpu-baseline --no-second-dataset --no-host-buffers --no-vlq --no-imi --no-deep1b > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 echo "trace done" >&2
 (cd $REPO && $T 600 bash profiles/pmc_passes.sh $OUT/pmc --no-second-dataset) > $OUT/pmc.log 2>&1
 python $REPO/profiles/summarize_pmc.py $OUT/pmc > $OUT/pmc_summary.txt
