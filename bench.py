@@ -949,7 +949,9 @@ def main():
                 traffic_source = "null: %s was measured on another setting of the data generator" % tname
             elif tj.get("sources_sha256") == sources_sha():
                 traffic = tj["hbm_bytes_per_launch"]
-                traffic_source = "%s (rocprofv3 --pmc passes of this command, same kernel sources)" % tname
+                at = tj.get("kernel_ms_in_same_refresh_run")
+                traffic_source = "%s (rocprofv3 --pmc passes of this command, same kernel sources%s)" % (
+                    tname, "; the kernel averaged %.4f ms in that run's kernel trace" % at if at else "")
             else:
                 traffic_source = "null: scan-kernel sources changed since %s was taken" % tname
         except Exception:

@@ -111,5 +111,14 @@ try:
     out["generator"] = json.load(open(dst("bench.json")))["dataset"]["generator_flags"]
 except Exception:
     out["generator"] = [0.005, 12, 0.4] if R >= "r04" else list(bench.G1_FLAGS)
+# the kernel's average duration in the kernel trace of the same refresh run (bench_kernel_stats.csv): the time these bytes go with
+try:
+    import csv as _csv
+    for r in _csv.reader(open(dst("bench_kernel_stats.csv"))):
+        if r and r[0].startswith(out["kernel"][:40]):
+            out["kernel_ms_in_same_refresh_run"] = float(r[3]) / 1e6
+            break
+except Exception:
+    pass
 json.dump(out, open(dst("scan_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -301,6 +301,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
+    int64_t screened_rows = 0;       // rows that went through the two-pass screen (either half), counted once behind the join
     for (int m = 0; m < 2; m++) {
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
         float* tmin = nullptr;
@@ -377,7 +378,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
                 HIP_TRY(hipEventRecord(h->imi_join, st));
                 HIP_TRY(hipStreamWaitEvent(h->stream, h->imi_join, 0));
             }
-            if (m == 1) TRY(screen_counters_copy(h, 2 * n));
+            screened_rows += n;
             continue;
         }
         if (dc < 16) {
@@ -404,6 +405,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
         else if (T > 1024) vlq::launch_row_select_sorted(tab[m], n, kc, kc, T, sv[m], si[m], h->stream);   // (imi_wide.hip; checked by the caller)
         else vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
     }
+    if (screened_rows > 0) TRY(screen_counters_copy(h, screened_rows));      // (both chains have joined the index's stream)
     vlq::launch_imi_minsum(sv[0], si[0], sv[1], si[1], T, n, k, kc, h->imi_nbits, hv, hi, cdis_dev, keys_dev,
                            h->stream);
     HIP_TRY(hipGetLastError());
@@ -719,9 +721,15 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 }
             }
             tm.stop();
-            snprintf(h->last_scan, sizeof(h->last_scan), "%s", vlq::last_scan16_shape());
-            h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit; h->last_walk_flag = a.walk_flag;
+            if (h->ntotal >= (int64_t)h->nlist * 24) snprintf(h->last_scan, sizeof(h->last_scan), "%s", vlq::last_scan16_shape());
+            h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit;
             h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
+            // (the 32 counts the order was decided from: copied now -- a later search may grow, i.e. free, the buffer they live in)
+            h->last_walk_counts = false;
+            if (a.walk_flag && h->walk_counts.reserve(32 * sizeof(int)) == VLQ_OK) {
+                HIP_TRY(hipMemcpyAsync(h->walk_counts.p, a.walk_flag, 32 * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+                h->last_walk_counts = true;
+            }
         } else if ((vlq::scanm_supports(a) || vlq::scanm0_supports(a)) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
             // 8 / 32 / 64-byte codes: the engineered organisation (scanm.hip); queries ordered like the 16-byte path
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
@@ -737,10 +745,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             StageTimer tm(h, 2);
             vlq::launch_scanm(a, h->stream);
             tm.stop();
+            snprintf(h->last_scan, sizeof(h->last_scan), "scanm_kernel<%d>", h->M);
+            h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit;
+            h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
+            h->last_walk_counts = false;
+            if (a.walk_flag && h->walk_counts.reserve(32 * sizeof(int)) == VLQ_OK) {
+                HIP_TRY(hipMemcpyAsync(h->walk_counts.p, a.walk_flag, 32 * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+                h->last_walk_counts = true;
+            }
         } else {
             StageTimer tm(h, 2);
             vlq::launch_scan(a, h->stream);
             tm.stop();
+            snprintf(h->last_scan, sizeof(h->last_scan), "scan_kernel");
+            h->last_walk_first = -1; h->last_walk_limit = 0; h->last_walk_samples = 0; h->last_walk_counts = false;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -859,7 +877,7 @@ void vlq_ivfpq_destroy(vlq_ivfpq_t h) {
                       &h->ws_own_count, &h->ws_part_mask, &h->ws_part_keys, &h->ws_own_recs, &h->ws_own_seg, &h->ws_own_items, &h->coarse_s, &h->cnorm_s, &h->ws_cand, &h->ws_cnt, &h->ws_Dp, &h->ws_Ip, &h->ws_append.cnt, &h->ws_append.cstart, &h->ws_append.keys_in,
                       &h->ws_append.keys_out, &h->ws_append.sort_tmp, &h->ws_x, &h->ws_qn, &h->ws_dist, &h->ws_keys, &h->ws_cdis,
                       &h->ws_qtab, &h->ws_D, &h->ws_I, &h->ws_misc, &h->ws_keys_in, &h->ws_cdis_in,
-                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent, &h->ws_Dr, &h->ws_Ir, &h->ws_keys_run, &h->ws_cdis_run,
+                      &h->ws_codes, &h->ws_assign, &h->ws_hist, &h->ws_qorder, &h->ws_tmin, &h->walk_state, &h->stats, &h->imi_cent, &h->ws_Dr, &h->ws_Ir, &h->ws_keys_run, &h->ws_cdis_run, &h->walk_counts,
                       &h->imi_norm, &h->imi_virtual, &h->ws_imi,
                       // the float16 screen of the coarse stage: built for every index at set_coarse_centroids
                       &h->screen.half, &h->screen.mu, &h->screen.norm_c, &h->imi_screen[0].half, &h->imi_screen[0].mu,
@@ -1404,9 +1422,9 @@ int vlq_ivfpq_last_scan_info(vlq_ivfpq_t h, char* buf, int cap) {
     int shared = -1;
     if (h->last_walk_first >= 0) {
         order = "list-id walk";
-        if (h->last_walk_flag) {        // decided on the device from walk_stat_kernel's counts
+        if (h->last_walk_counts) {      // decided on the device from walk_stat_kernel's counts (the handle's own copy of them)
             int v[32];
-            HIP_TRY(hipMemcpy(v, h->last_walk_flag, sizeof(v), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(v, h->walk_counts.p, sizeof(v), hipMemcpyDeviceToHost));
             shared = 0;
             for (int x : v) shared += x;
             if (shared > h->last_walk_limit) order = "coarse-distance order";

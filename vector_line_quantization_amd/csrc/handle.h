@@ -151,7 +151,8 @@ struct vlq_ivfpq_s {
     // device-side statistic it was decided from (32 counts behind the scan order)
     char last_scan[64] = "";
     int last_walk_first = -1, last_walk_limit = 0, last_walk_samples = 0;
-    const int* last_walk_flag = nullptr;
+    bool last_walk_counts = false;   // walk_counts holds the 32 counts of the last launch's walk statistic
+    DevBuf walk_counts;
     // float16 look-up tables of the plain IVFPQ scan (vlq_ivfpq_set_float16_tables): half(term2), per-page half(term3)
     bool fp16_tables = false, term2h_valid = false;
     DevBuf term2h, ws_qtabh;

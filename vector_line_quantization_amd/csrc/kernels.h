@@ -164,7 +164,6 @@ void launch_scanm(const ScanArgs& a, hipStream_t s);
 // specialisation for M = 16, ksub = 256, table_mode = 1 (scan16.hip)
 void launch_scan16(const ScanArgs& a, hipStream_t s);
 const char* last_scan16_shape();      // "scan16_kernel<KPL, NW, NBUF, PIPE, IMI, OWNED>" of this thread's last launch
-const char* last_scan16_shape();      // "scan16_kernel<KPL, NW, NBUF, PIPE, IMI, OWNED>" of this thread's last launch
 // list-owned schedule of the same kernel: launch_owned_order prepares own_order / own_count / part_mask,
 // launch_qtab16 the per-query table (-2 <q_m, cent_mj>, [nq][16][256]), launch_scan16_owned scans the
 // (query, partition) items and launch_owned_merge writes the final rows
