@@ -115,7 +115,7 @@ except Exception:
 try:
     import csv as _csv
     for r in _csv.reader(open(dst("bench_kernel_stats.csv"))):
-        if r and r[0].startswith(out["kernel"][:40]):
+        if r and out["kernel"][:40] in r[0]:
             out["kernel_ms_in_same_refresh_run"] = float(r[3]) / 1e6
             break
 except Exception:
