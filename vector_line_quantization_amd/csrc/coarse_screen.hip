@@ -1090,4 +1090,9 @@ void launch_coarse_screened_nn(const float* q, const void* q_half, const unsigne
                        qn_c, q_flags, d, cmax, cmax0, c_sub, exact_rows);
 }
 
+void preload_coarse_screen_kernels() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(screen_prep_kernel));
+}
+
 }  // namespace vlq

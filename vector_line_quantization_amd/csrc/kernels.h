@@ -10,6 +10,12 @@ namespace vlq {
 // the CURRENT device.  The attribute is per device and the library may serve several devices
 // (and host threads) of one process, so the high-water mark is kept per (kernel, device).
 void ensure_dynamic_lds(const void* kernel, size_t bytes);
+// loads the code objects of the search path's kernels (the runtime loads a translation unit's code object at the first use of one
+// of its kernels: ~0.2-0.5 ms each); called with the lists, so that a caller's first search does not pay for it
+void preload_search_kernels();
+void preload_scan16_kernels();       // scan16.hip
+void preload_coarse_screen_kernels();  // coarse_screen.hip
+void preload_scanm_kernels();        // scanm.hip
 
 // row norms in the reference's SSE order (utils.cpp:538-556, :675-682)
 void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s);

@@ -48,6 +48,18 @@ __global__ void row_norms_kernel(const float* __restrict__ x, int64_t n, int d,
     out[i] = norm_sse_order([&](int c) { return xi[c]; }, d);
 }
 
+void preload_search_kernels() {
+    static bool done = false;           // (per process: the code objects stay loaded)
+    if (done) return;
+    done = true;
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(row_norms_kernel));
+    preload_scan16_kernels();
+    preload_coarse_screen_kernels();
+    preload_scanm_kernels();
+    (void)hipGetLastError();
+}
+
 void launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n,

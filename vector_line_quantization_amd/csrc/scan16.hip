@@ -1076,6 +1076,11 @@ __global__ __launch_bounds__(256) void walk_stat_kernel(const int64_t* __restric
     if (t == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+void preload_scan16_kernels() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(qorder_hist_kernel));
+}
+
 // returns the number of (pair, probe) samples behind the 32 counts in part[]
 int walk_stat_samples(int64_t nq, int nprobe) { return (int)std::min<int64_t>(256, nq - 1) * std::min(nprobe, 32); }
 

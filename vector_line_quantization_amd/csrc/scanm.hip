@@ -656,4 +656,9 @@ void launch_scanm(const ScanArgs& a_in, hipStream_t s) {
     }
 }
 
+void preload_scanm_kernels() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scanm_kernel<8, 1, 2, false, 0, 0>));
+}
+
 }  // namespace vlq
