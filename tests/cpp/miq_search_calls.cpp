@@ -3,7 +3,8 @@
 // (interposer in front of the reference's library):
 //   * faiss::MultiIndexQuantizer::search(n, x, k > 1, ...)  -- a caller of its own (IndexIVFPQR::search does this) --
 //     lands in vlq_ivfpq_coarse_search of the handle that holds the quantizer's sub-centroids;
-//   * faiss::IndexIVFPQ::search with nprobe beyond 1024 is served whole (coarse stage + scan in runs).
+//   * faiss::IndexIVFPQ::search with nprobe beyond 1024 is served whole (coarse stage + scan in runs);
+//   * faiss::IndexIVFPQ::search over a flat quantizer (BASELINE configs[1]'s class) is served whole too.
 // Each result is compared with the reference's own definition of the same member, reached through dlsym on the reference's
 // library: sub-vectors of 8 dimensions take the reference's SSE path (fvec_L2sqr, no BLAS) and must agree bit for bit --
 // cells, sums, neighbours, distances; sub-vectors of 16 and more go through the BLAS vendor's sgemm there, so cells agree
@@ -18,6 +19,7 @@
 #include <random>
 #include <vector>
 
+#include "IndexFlat.h"
 #include "IndexIVFPQ.h"
 #include "IndexPQ.h"
 
@@ -102,6 +104,43 @@ int main(int argc, char** argv) {
         const bool ok = exact ? (frac >= 0.9999 && relmax == 0) : (frac >= 0.995 && relmax <= 1e-4);
         printf("whole search nprobe=%zu: neighbours equal %.5f, distances rel. err %.2e -> %s\n", nprobe, frac, relmax, ok ? "ok" : "BAD");
         bad += !ok;
+    }
+    // 3. the same whole search over a FLAT quantizer (IndexIVFPQ(IndexFlatL2, ...): BASELINE configs[1]'s class): the reference's
+    // coarse stage is IndexFlat::search -> knn_L2sqr_blas for 20 and more queries (utils.cpp:834-901), whose sgemm order is the BLAS
+    // vendor's, so probes at the nprobe-th rank may swap with a near-tie: neighbours to >= 99.5 %, distances to 1e-4; with fewer
+    // than 20 queries both sides run fvec_L2sqr (utils.cpp:757-786) and must agree bit for bit
+    {
+        const size_t nl = 256;
+        faiss::IndexFlatL2 fq(d);
+        faiss::IndexIVFPQ fidx(&fq, d, nl, M, 8);
+        fidx.verbose = false;
+        fidx.train(nt, xt.data());
+        fidx.add(nb, xb.data());
+        fidx.precompute_table();
+        fidx.nprobe = 16;
+        typedef void (*flat_fn)(const faiss::IndexFlat*, idx_t, const float*, idx_t, float*, idx_t*);
+        flat_fn flat_ref = (flat_fn)dlsym(ref, "_ZNK5faiss9IndexFlat6searchElPKflPfPl");
+        if (!flat_ref) { fprintf(stderr, "dlsym IndexFlat::search failed\n"); return 2; }
+        for (size_t n : {size_t(7), nq}) {
+            const idx_t k = 20;
+            std::vector<float> D1(n * k), D0(n * k), cdis(n * fidx.nprobe);
+            std::vector<idx_t> I1(n * k), I0(n * k);
+            std::vector<long> keys(n * fidx.nprobe);
+            fidx.search(n, xq.data(), k, D1.data(), I1.data());
+            flat_ref(&fq, n, xq.data(), (idx_t)fidx.nprobe, cdis.data(), keys.data());
+            faiss::float_maxheap_array_t res = {n, (size_t)k, I0.data(), D0.data()};
+            knn_ref(&fidx, n, xq.data(), keys.data(), cdis.data(), &res, false);
+            size_t same = 0;
+            double relmax = 0;
+            for (size_t i = 0; i < n * (size_t)k; i++) {
+                same += I1[i] == I0[i];
+                if (I1[i] == I0[i] && D0[i] < 1e30f) relmax = std::max(relmax, (double)std::fabs(D1[i] - D0[i]) / std::max(1e-12, (double)std::fabs(D0[i])));
+            }
+            const double frac = (double)same / (double)(n * k);
+            const bool ok = n < 20 ? (same == n * (size_t)k && memcmp(D1.data(), D0.data(), D0.size() * 4) == 0) : (frac >= 0.995 && relmax <= 1e-4);
+            printf("flat quantizer, whole search, %zu queries: neighbours equal %.5f, distances rel. err %.2e -> %s\n", n, frac, relmax, ok ? "ok" : "BAD");
+            bad += !ok;
+        }
     }
     printf("miq_search_calls d=%d: %s\n", d, bad ? "FAILED" : "PASSED");
     return bad ? 1 : 0;

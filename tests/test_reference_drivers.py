@@ -247,4 +247,4 @@ def test_quantizer_and_whole_search_calls_of_a_user_program(d):
     print(p.stdout[-3000:], p.stderr[-600:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     m = re.search(r"whole_searches=(\d+) .*device_coarse_searches=(\d+)", p.stderr)
-    assert m and int(m.group(1)) == 3 and int(m.group(2)) == 4, p.stderr[-400:]
+    assert m and int(m.group(1)) == 5 and int(m.group(2)) == 4, p.stderr[-400:]        # 3 multi-index + 2 flat whole searches
