@@ -515,13 +515,20 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 // the workgroups' own walk times, per XCD; a new (nprobe, k, batch class) starts measuring afresh
                 if (!h->walk_state.p) { TRY(h->walk_state.reserve(8 * 16 * sizeof(int))); h->walk_key = -1; }
                 const int64_t wkey = ((int64_t)nprobe << 32) ^ ((int64_t)k << 16) ^ (int64_t)(ni >= 4096 ? 2 : 1);
-                if (wkey != h->walk_key) { (void)hipMemsetAsync(h->walk_state.p, 0, 8 * 16 * sizeof(int), h->stream); h->walk_key = wkey; }
+                if (wkey != h->walk_key) { (void)hipMemsetAsync(h->walk_state.p, 0, 8 * 16 * sizeof(int), h->stream); h->walk_key = wkey; h->walk_stat_calls = 0; }
                 a.walk_state = h->walk_state.as<int>();
             }
         }
         // the statistic is computed with the scan order (launch_query_order); behind the order's ni entries: its 32 counts
         const bool walk_auto = wf_env < -1 && a.walk_first >= 0;
-        auto walk_part = [&]() -> int* { return walk_auto ? h->ws_qorder.as<int>() + ((ni + 3) & ~(int64_t)3) : nullptr; };
+        // (the counts live in the handle: the statistic describes the workload, not one batch -- it is sampled on the first
+        // four searches of a (nprobe, k, batch class) and on every 16th after that, 6.4 us + a launch gap otherwise saved per
+        // search; VLQ_WALK_STAT_EVERY=1: every search.  Speed only: the results do not depend on the walking order)
+        if (walk_auto) TRY(h->walk_counts.reserve(32 * sizeof(int)));
+        static const int stat_every = [] { const char* e = getenv("VLQ_WALK_STAT_EVERY"); return e ? std::max(1, atoi(e)) : 16; }();
+        const bool walk_stat_now = walk_auto && (h->walk_stat_calls < 4 || h->walk_stat_calls % stat_every == 0);
+        if (walk_auto) h->walk_stat_calls++;
+        auto walk_part = [&]() -> int* { return walk_auto ? h->walk_counts.as<int>() : nullptr; };
         // a launch with no measured walk time seeds its clock period from a model (walk_stat_kernel): the workgroups that will
         // share the chip = the scan kernels' slots (scan16.hip: 2048 two-wave / 1280 four-wave workgroups), at most the batch
         vlq::WalkSeed wseed;
@@ -654,7 +661,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -724,12 +731,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             if (h->ntotal >= (int64_t)h->nlist * 24) snprintf(h->last_scan, sizeof(h->last_scan), "%s", vlq::last_scan16_shape());
             h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit;
             h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
-            // (the 32 counts the order was decided from: copied now -- a later search may grow, i.e. free, the buffer they live in)
-            h->last_walk_counts = false;
-            if (a.walk_flag && h->walk_counts.reserve(32 * sizeof(int)) == VLQ_OK) {
-                HIP_TRY(hipMemcpyAsync(h->walk_counts.p, a.walk_flag, 32 * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-                h->last_walk_counts = true;
-            }
+            h->last_walk_counts = a.walk_flag != nullptr;       // (the 32 counts the order was decided from live in the handle)
         } else if ((vlq::scanm_supports(a) || vlq::scanm0_supports(a)) && h->ntotal >= (int64_t)h->nlist * 24 && !getenv("VLQ_GENERIC_SCAN")) {
             // 8 / 32 / 64-byte codes: the engineered organisation (scanm.hip); queries ordered like the 16-byte path
             if (ni >= 1024 && h->nlist <= (1 << 22)) {
@@ -737,7 +739,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -748,11 +750,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             snprintf(h->last_scan, sizeof(h->last_scan), "scanm_kernel<%d>", h->M);
             h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit;
             h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
-            h->last_walk_counts = false;
-            if (a.walk_flag && h->walk_counts.reserve(32 * sizeof(int)) == VLQ_OK) {
-                HIP_TRY(hipMemcpyAsync(h->walk_counts.p, a.walk_flag, 32 * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-                h->last_walk_counts = true;
-            }
+            h->last_walk_counts = a.walk_flag != nullptr;
         } else {
             StageTimer tm(h, 2);
             vlq::launch_scan(a, h->stream);
@@ -1453,6 +1451,7 @@ int vlq_ivfpq_reset_walk_state(vlq_ivfpq_t h) {
     if (!h) return fail(VLQ_ERR_INVALID, "null handle");
     TRY(set_dev(h));
     if (h->walk_state.p) HIP_TRY(hipMemsetAsync(h->walk_state.p, 0, 8 * 16 * sizeof(int), h->stream));
+    h->walk_stat_calls = 0;
     return VLQ_OK;
 }
 

@@ -213,8 +213,9 @@ int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int npr
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank = nullptr, int* walk_part = nullptr, int* walk_state = nullptr,
-                        WalkSeed seed = WalkSeed());
-// walk_part (optional): the walking-order statistic (32 counts, see launch_walk_stat) is computed along with the order
+                        WalkSeed seed = WalkSeed(), bool run_walk_stat = true);
+// walk_part (optional): the walking-order statistic (32 counts, see launch_walk_stat) is computed along with the order when
+// run_walk_stat (otherwise the counts of an earlier search stay and the placement kernel freezes this launch's clock period)
 int walk_stat_samples(int64_t nq, int nprobe);
 
 // merge of per-shard results [nparts][nq][k] into the global top-k (list-sharded multi-GPU mode)

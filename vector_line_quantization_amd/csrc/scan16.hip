@@ -910,8 +910,14 @@ __global__ void qorder_hist_kernel(const int64_t* __restrict__ keys, int64_t nq,
 __global__ __launch_bounds__(256) void qorder_place_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe,
                                                            int nlist, const int* __restrict__ hist,
                                                            int* __restrict__ cnt, int* __restrict__ qorder,
-                                                           const int* __restrict__ list_rank, int shift, int nbins) {
+                                                           const int* __restrict__ list_rank, int shift, int nbins, int* walk_freeze) {
     extern __shared__ int pre[];                 // [nbins] exclusive prefix
+    // a search that does not re-sample the walking statistic still freezes this launch's clock period per XCD = the running
+    // mean of the walk times measured so far (walk_stat_kernel does it otherwise)
+    if (walk_freeze && blockIdx.x == 0 && threadIdx.x < 8) {
+        const int mean = walk_freeze[threadIdx.x * 16];
+        if (mean > 0) walk_freeze[threadIdx.x * 16 + 1] = mean;
+    }
     __shared__ int part[256];
     const int t = threadIdx.x;
     const int per = (nbins + 255) / 256;
@@ -958,8 +964,12 @@ __device__ __forceinline__ int walk_stat_sample(const int64_t* __restrict__ keys
 
 __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __restrict__ keys, int nq, int nprobe, int nlist,
                                                              int* __restrict__ qorder, const int* __restrict__ list_rank,
-                                                             int shift, int nbins) {
+                                                             int shift, int nbins, int* walk_freeze) {
     extern __shared__ int cnt[];                 // [nbins] counts, then running offsets
+    if (walk_freeze && threadIdx.x < 8) {        // (see qorder_place_kernel)
+        const int mean = walk_freeze[threadIdx.x * 16];
+        if (mean > 0) walk_freeze[threadIdx.x * 16 + 1] = mean;
+    }
     __shared__ int wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int b = t; b < nbins; b += 1024) cnt[b] = 0;
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __re
 }
 
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state, WalkSeed seed) {
+                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state, WalkSeed seed, bool run_walk_stat) {
     if (nq <= 0) return;
     // at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
     // by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
@@ -1005,9 +1015,9 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
         const size_t smem1 = (size_t)nbins * sizeof(int);
         ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_single_kernel), smem1);
         hipLaunchKernelGGL(qorder_single_kernel, dim3(1), dim3(1024), smem1, s, keys, (int)nq, nprobe, nlist, qorder, list_rank,
-                           shift, nbins);
+                           shift, nbins, (walk_part && !run_walk_stat) ? walk_state : nullptr);
         // (the statistic inside this one-workgroup kernel was measured: 8192 samples on one CU cost 36 us against 5)
-        if (walk_part && nq >= 2) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
+        if (walk_part && nq >= 2 && run_walk_stat) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
         return;
     }
     const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
@@ -1018,8 +1028,8 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
     const size_t smem = (size_t)nbins * sizeof(int);
     ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
     hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
-                       hist + stride, qorder, list_rank, shift, nbins);
-    if (walk_part) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
+                       hist + stride, qorder, list_rank, shift, nbins, (walk_part && !run_walk_stat) ? walk_state : nullptr);
+    if (walk_part && run_walk_stat) launch_walk_stat(keys, qorder, nq, nprobe, walk_part, walk_state, s, seed);
 }
 
 // ---------------------------------------------------------------------------
