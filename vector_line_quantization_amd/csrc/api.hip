@@ -239,7 +239,7 @@ int coarse_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int nprobe, float*
                                     h->ws_dist.as<float>(), h->ws_tmin.p ? h->ws_tmin.as<float>() : nullptr, h->ws_cand.p, n, h->nlist,
                                     h->d, nprobe, h->screen.scale, h->screen.cmax, h->screen.cmax0, cdis_dev, keys_dev,
                                     h->ws_kept.p ? h->ws_kept.as<unsigned long long>() : nullptr, h->ws_screen_cnt.as<unsigned int>(),
-                                    h->stream);
+                                    h->stream, h->order_hist, &h->order_hist_ready);
         TRY(screen_counters_copy(h, n));
         HIP_TRY(hipGetLastError());
         return VLQ_OK;
@@ -661,7 +661,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(),
                                         h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now, h->order_hist_ready && ni == n);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -739,7 +739,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
                 TRY(h->ws_hist.reserve(2 * vlq::query_order_bins_padded(h->nlist) * sizeof(int)));
                 TRY(h->ws_qorder.reserve(((size_t)ni + 40) * sizeof(int)));
                 vlq::launch_query_order(a.keys, ni, nprobe, h->nlist, h->ws_hist.as<int>(), h->ws_qorder.as<int>(), h->stream,
-                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now);
+                                        (h->have_rank && h->imi_nbits == 0) ? h->list_rank.as<int>() : nullptr, walk_part(), a.walk_state, wseed, walk_stat_now, h->order_hist_ready && ni == n);
                 a.qorder = h->ws_qorder.as<int>();
                 walk_decide();
                 tq.stop();
@@ -761,6 +761,7 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
     }
     HIP_TRY(hipGetLastError());
     h->stat_nq += (uint64_t)n;
+    h->order_hist_ready = false;
     return VLQ_OK;
 }
 
@@ -1289,6 +1290,7 @@ int vlq_ivfpq_search_preassigned(vlq_ivfpq_t h, int64_t n, const float* x, const
     if (n > 0 && (!keys || !coarse_dis)) return fail(VLQ_ERR_INVALID, "null keys/coarse_dis");
     if (n == 0) return VLQ_OK;
     TRY(set_dev(h));
+    h->order_hist_ready = false;              // (the caller's keys: no histogram came with them)
     const void *xd, *kd, *cd;
     TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
     TRY(stage_in(h, keys, (size_t)n * nprobe * 8, h->ws_keys_in, &kd));
@@ -1335,8 +1337,22 @@ int vlq_ivfpq_search(vlq_ivfpq_t h, int64_t n, const float* x, int nprobe, int k
     TRY(stage_out(I, (size_t)n * k * 8, h->ws_I, &Id, &copyI, &zcI));
     const void* xd = nullptr;
     TRY(stage_in(h, x, (size_t)n * h->d * 4, h->ws_x, &xd));
+    // the scan order's histogram rides on the coarse stage's last kernel when one coarse page and one scan page serve the batch
+    // (kernels.h OrderHist; the single-workgroup ordering of small batches does not use it)
+    h->order_hist = vlq::OrderHist();
+    h->order_hist_ready = false;
+    if (h->imi_nbits == 0 && n > 2048 && n <= 32768 && n <= query_page(h) && h->nlist <= (1 << 22) && !getenv("VLQ_ORDER_HIST_OFF")) {
+        const size_t stride = vlq::query_order_bins_padded(h->nlist);
+        TRY(h->ws_hist.reserve(2 * stride * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(h->ws_hist.p, 0, 2 * stride * sizeof(int), h->stream));
+        h->order_hist.hist = h->ws_hist.as<int>();
+        h->order_hist.list_rank = h->have_rank ? h->list_rank.as<int>() : nullptr;
+        h->order_hist.nlist = h->nlist;
+        vlq::query_order_bins(h->nlist, &h->order_hist.shift, &h->order_hist.nbins);
+    }
     // IndexIVFPQ::search (IndexIVFPQ.cpp:1063-1081): quantizer->search, then search_knn_with_key
     TRY(coarse_dev(h, n, (const float*)xd, nprobe, h->ws_cdis.as<float>(), h->ws_keys.as<int64_t>()));
+    h->order_hist.hist = nullptr;            // (only this call's coarse stage may add to the counts)
     TRY(scan_runs_dev(h, n, (const float*)xd, h->ws_keys.as<int64_t>(), h->ws_cdis.as<float>(), nprobe, k,
                       (float*)Dd, (int64_t*)Id, 0));
     TRY(finish_outputs(h, copyD, D, Dd, (size_t)n * k * 4, copyI, I, Id, (size_t)n * k * 8));

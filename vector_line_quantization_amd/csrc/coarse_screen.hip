@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
                                                                   unsigned long long* __restrict__ kept_total,
                                                                   const uint32_t* __restrict__ bits = nullptr,
                                                                   const unsigned char* __restrict__ rflag = nullptr,
-                                                                  unsigned int* __restrict__ exact_rows = nullptr) {
+                                                                  unsigned int* __restrict__ exact_rows = nullptr, OrderHist oh = OrderHist()) {
     __shared__ u64 queue[4][64];
     __shared__ uint32_t cand[4][kKeepCap];
     __shared__ __attribute__((aligned(16))) float qrow[4][128];
@@ -860,6 +860,11 @@ __global__ __launch_bounds__(256) void coarse_screen_exact_kernel(const uint32_t
             const bool miss = key == kMaxKey;
             cdis[q * nprobe + e] = miss ? FLT_MAX_F : ordered_to_f32((uint32_t)(key >> 32));
             keys[q * nprobe + e] = miss ? -1 : (int64_t)(uint32_t)key;
+            if (e == 0 && oh.hist) {            // the scan order's histogram over the rows' nearest centroids (qorder_hist_kernel's bins)
+                const int64_t k0 = miss ? -1 : (int64_t)(uint32_t)key;
+                const bool ok = k0 >= 0 && k0 < oh.nlist;
+                atomicAdd(&oh.hist[ok ? ((oh.list_rank ? oh.list_rank[k0] : (int)k0) >> oh.shift) : oh.nbins - 1], 1);
+            }
         }
     }
 }
@@ -963,7 +968,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
                             float* approx /* [roundup128(nq)][nlist] halves */, float* tmin_ws /* nlist > 8192: [nq][nlist / 64] */,
                             void* keep_ws, int64_t nq,
                             int nlist, int d, int nprobe, float scale, float cmax, float cmax0, float* cdis, int64_t* keys,
-                            unsigned long long* kept_total, unsigned int* exact_rows, hipStream_t s) {
+                            unsigned long long* kept_total, unsigned int* exact_rows, hipStream_t s, OrderHist oh, bool* hist_done) {
+    if (hist_done) *hist_done = false;
     if (nq <= 0) return;
     const int ks = (d + 15) / 16;
     const float inv_s2 = 1.f / (scale * scale);                // a power of two
@@ -1006,7 +1012,8 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
         if (npool <= 64) VLQ_CUT(1); else if (npool <= 128) VLQ_CUT(2); else if (npool <= 256) VLQ_CUT(4); else if (npool <= 512) VLQ_CUT(8); else VLQ_CUT(16);
         VLQ_KS(VLQ_STR1)
         hipLaunchKernelGGL((coarse_screen_exact_kernel<1, true>), sgrid, block, 0, s, (const uint32_t*)nullptr, (const uint16_t*)nullptr, nq, nlist,
-                           nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows);
+                           nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows, oh);
+        if (hist_done) *hist_done = oh.hist != nullptr;
 #undef VLQ_STR0
 #undef VLQ_STR1
 #undef VLQ_KS

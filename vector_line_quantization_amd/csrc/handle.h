@@ -147,6 +147,8 @@ struct vlq_ivfpq_s {
     DevBuf ws_x, ws_qn, ws_dist, ws_keys, ws_cdis, ws_qtab, ws_D, ws_I, ws_misc, ws_keys_in,
         ws_cdis_in, ws_codes, ws_assign, ws_hist, ws_qorder, ws_tmin, walk_state;
     int64_t walk_key = -1;       // (nprobe, k, batch class) the walk times in walk_state were measured for
+    vlq::OrderHist order_hist;   // the scan order's histogram taken along by the coarse stage (vlq_ivfpq_search only)
+    bool order_hist_ready = false;
     int64_t walk_stat_calls = 0; // searches of that key so far (the neighbour-sharing statistic is re-sampled on some of them only)
     // what the last search_dev scan launch was (vlq_ivfpq_last_scan_info): kernel shape, the walking-order rule and the
     // device-side statistic it was decided from (32 counts behind the scan order)

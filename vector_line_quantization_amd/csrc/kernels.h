@@ -53,6 +53,11 @@ void launch_coarse_screened_nn(const float* q, const void* q_half, const unsigne
                                hipStream_t s);
 size_t coarse_screen_keep_bytes(int64_t nq, int nlist);      // keep_ws of launch_coarse_screened
 bool coarse_screen_matrix_free_ok(int nlist, int nprobe);    // the screen without the half matrix (tmin_ws then always needed)
+// The scan order's histogram (launch_query_order: counting sort of the queries by their nearest centroid) taken along by the
+// coarse stage's last kernel, which holds every row's nearest centroid anyway: hist[bin(keys[q][0])] += 1 (hist zeroed by the
+// caller; the bins are launch_query_order's: query_order_bins).  One launch and its gap less per search.
+struct OrderHist { int* hist = nullptr; const int* list_rank = nullptr; int shift = 0, nbins = 0, nlist = 0; };
+void query_order_bins(int nlist, int* shift, int* nbins);
 // qn / cn: exact squared norms (reference order) of queries / centroids; qn_c / cn_c: of the centred ones; cmax = max |c - mu|
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
                             const float* qn, const float* cn, const float* qn_c, const float* cn_c, float* approx,
@@ -60,7 +65,7 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
                             int64_t nq, int nlist, int d, int nprobe, float scale, float cmax, float cmax0 /* max |c| */, float* cdis,
                             int64_t* keys,
                             unsigned long long* kept_total, unsigned int* exact_rows /* += rows the screen could not decide (optional) */,
-                            hipStream_t s);
+                            hipStream_t s, OrderHist oh = OrderHist(), bool* hist_done = nullptr /* set when the histogram was taken */);
 
 // filtered coarse stage (no distance matrix; kernels.hip): a sample of the column tiles (stride s) gives every
 // row an exact upper bound of its nprobe-th smallest distance, the full pass keeps only the elements at or
@@ -213,7 +218,7 @@ int launch_walk_stat(const int64_t* keys, const int* qorder, int64_t nq, int npr
 // list_rank (optional): bins are the spatial ranks of the lists instead of the list ids
 void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
                         int* qorder, hipStream_t s, const int* list_rank = nullptr, int* walk_part = nullptr, int* walk_state = nullptr,
-                        WalkSeed seed = WalkSeed(), bool run_walk_stat = true);
+                        WalkSeed seed = WalkSeed(), bool run_walk_stat = true, bool hist_ready = false);
 // walk_part (optional): the walking-order statistic (32 counts, see launch_walk_stat) is computed along with the order when
 // run_walk_stat (otherwise the counts of an earlier search stay and the placement kernel freezes this launch's clock period)
 int walk_stat_samples(int64_t nq, int nprobe);

@@ -1003,14 +1003,21 @@ __global__ __launch_bounds__(1024) void qorder_single_kernel(const int64_t* __re
     for (int q = t; q < nq; q += 1024) qorder[atomicAdd(&cnt[bin_of(q)], 1)] = q;
 }
 
-void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
-                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state, WalkSeed seed, bool run_walk_stat) {
-    if (nq <= 0) return;
-    // at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
-    // by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
+// at most 16 Ki bins (the prefix is recomputed per workgroup in LDS): many-list indexes are binned
+// by the high bits of the list id / rank -- for a multi-index key that is its second sub-index
+void query_order_bins(int nlist, int* shift_out, int* nbins_out) {
     int shift = 0;
     while (((int64_t)nlist >> shift) > 16384) shift++;
-    const int nbins = (int)(((int64_t)nlist - 1) >> shift) + 2;        // last bin: invalid keys
+    *shift_out = shift;
+    *nbins_out = (int)(((int64_t)nlist - 1) >> shift) + 2;        // last bin: invalid keys
+}
+
+void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, int* hist,
+                        int* qorder, hipStream_t s, const int* list_rank, int* walk_part, int* walk_state, WalkSeed seed, bool run_walk_stat,
+                        bool hist_ready) {
+    if (nq <= 0) return;
+    int shift, nbins;
+    query_order_bins(nlist, &shift, &nbins);
     if (nq <= 2048) {
         const size_t smem1 = (size_t)nbins * sizeof(int);
         ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_single_kernel), smem1);
@@ -1021,10 +1028,12 @@ void launch_query_order(const int64_t* keys, int64_t nq, int nprobe, int nlist, 
         return;
     }
     const size_t stride = query_order_bins_padded(nlist);               // hist | cnt, one aligned memset
-    (void)hipMemsetAsync(hist, 0, 2 * stride * sizeof(int), s);
     const unsigned g = (unsigned)((nq + 255) / 256);
-    hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank,
-                       shift, nbins);
+    if (!hist_ready) {          // (otherwise the coarse stage's last kernel left the counts: OrderHist, kernels.h)
+        (void)hipMemsetAsync(hist, 0, 2 * stride * sizeof(int), s);
+        hipLaunchKernelGGL(qorder_hist_kernel, dim3(g), dim3(256), 0, s, keys, nq, nprobe, nlist, hist, list_rank,
+                           shift, nbins);
+    }
     const size_t smem = (size_t)nbins * sizeof(int);
     ensure_dynamic_lds(reinterpret_cast<const void*>(qorder_place_kernel), smem);
     hipLaunchKernelGGL(qorder_place_kernel, dim3(g), dim3(256), smem, s, keys, nq, nprobe, nlist, hist,
