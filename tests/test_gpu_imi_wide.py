@@ -109,3 +109,51 @@ def test_whole_search_with_more_than_1024_probes(nbits, dc, Mpq, nb, nprobe, k):
     with pytest.raises(Exception):                          # max_codes would apply per run, not to the whole probe list
         g.search(xq, nprobe, k)
     g.close()
+
+
+@pytest.mark.parametrize("nbits,d,Mpq,nb,nprobe,k", [
+    (11, 16, 8, 150000, 64, 10),          # the multi-index drivers' 8-byte codes on sparse lists
+    (11, 16, 8, 150000, 300, 100),
+    (11, 16, 4, 150000, 64, 10),
+    (11, 96, 12, 150000, 64, 10),         # Deep1B's dimension: 8-dimensional sub-vectors, 48-dimensional halves
+    (11, 96, 24, 150000, 64, 128),
+    (11, 96, 32, 150000, 64, 10),
+    (11, 128, 64, 150000, 32, 300),
+    (0, 32, 8, 100000, 48, 10),           # flat quantizer, 65 536 lists: the same kernel without table type 2
+])
+def test_sparse_lists_of_the_other_code_sizes(nbits, d, Mpq, nb, nprobe, k):
+    """A few codes per list with a code size other than 16 bytes (tests/sift1b_imi_pq.cpp and tests/deep1b_imi_pq.cpp ship 8-byte
+    codes on 2^28 lists): scanm_short_kernel -- no table per probe, every lane fetches the entries its code addresses -- against
+    the oracle bit for bit, and against the generic kernel that served these indexes until round 6."""
+    rng = np.random.default_rng(nbits * 1000 + d + Mpq)
+    cent = rng.random((40, d), dtype=np.float32)
+    xb = (cent[rng.integers(0, 40, nb)] + 0.05 * rng.standard_normal((nb, d))).astype(np.float32)
+    xq = (cent[rng.integers(0, 40, 120)] + 0.05 * rng.standard_normal((120, d))).astype(np.float32)
+    pq = (0.05 * rng.standard_normal((Mpq, 256, d // Mpq))).astype(np.float32)
+    if nbits:
+        kc, dc = 1 << nbits, d // 2
+        nlist = kc * kc
+        imi = np.stack([xb[rng.choice(nb, kc, replace=False), :dc], xb[rng.choice(nb, kc, replace=False), dc:]]).astype(np.float32)
+        g = vlq.GpuIVFPQ(d, nlist, Mpq, 8)
+        g.set_imi_centroids(nbits, imi)
+        ox = OracleIndex(d, nlist, Mpq, 8, None, pq, imi_centroids=imi, imi_nbits=nbits, by_residual=1, use_precomputed_table=2)
+    else:
+        nlist = 65536
+        coarse = (cent[rng.integers(0, 40, nlist)] + 0.05 * rng.standard_normal((nlist, d))).astype(np.float32)
+        g = vlq.GpuIVFPQ(d, nlist, Mpq, 8)
+        g.set_coarse_centroids(coarse)
+        ox = OracleIndex(d, nlist, Mpq, 8, coarse, pq, by_residual=1, use_precomputed_table=1)
+    g.set_pq_centroids(pq)
+    g.set_search_options(by_residual=True, use_precomputed_table=1)
+    g.add(xb)
+    ox.add(xb, canonical=True)
+    D, I = g.search(xq, nprobe, k)
+    assert "scanm_short_kernel<%d>" % Mpq in g.last_scan_info()
+    Do, Io, keyso, cdo = ox.search(xq, nprobe, k, canonical=True, return_coarse=True)
+    assert_same_topk(D, I, Do, Io, "sparse lists, %d-byte codes" % Mpq)
+    _n, ncode = g.stats(reset=True)
+    assert ncode == ox.last_ncode
+    Dp, Ip = g.search_preassigned(xq, keyso, cdo, k, store_pairs=True)
+    Dpo, Ipo = ox.search_preassigned(xq, keyso, cdo, k, store_pairs=True, canonical=True)
+    assert_same_topk(Dp, Ip, Dpo, Ipo, "sparse lists, store_pairs")
+    g.close()

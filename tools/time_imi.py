@@ -10,7 +10,7 @@ import numpy as np, torch
 import vector_line_quantization_amd as vlq
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 E = lambda k, v: int(os.environ.get(k, v))
-nbits, nb, nprobe, k, d, M = E("NBITS", 10), E("NB", 4000000), E("NPROBE", 64), E("K", 10), 128, 16
+nbits, nb, nprobe, k, d, M = E("NBITS", 10), E("NB", 4000000), E("NPROBE", 64), E("K", 10), E("DIM", 128), E("M", 16)
 nlist = 1 << (2 * nbits)
 rng = np.random.default_rng(0)
 g = vlq.GpuIVFPQ(d, nlist, M, 8)

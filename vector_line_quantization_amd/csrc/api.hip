@@ -751,6 +751,14 @@ int scan_dev(vlq_ivfpq_t h, int64_t n, const float* x_dev, const int64_t* keys_d
             h->last_walk_first = a.walk_first; h->last_walk_limit = a.walk_limit;
             h->last_walk_samples = a.walk_flag ? vlq::walk_stat_samples(ni, nprobe) : 0;
             h->last_walk_counts = a.walk_flag != nullptr;
+        } else if (h->M != 16 && h->ntotal < (int64_t)h->nlist * 24 && vlq::scanm_short_supports(a) && !getenv("VLQ_GENERIC_SCAN")) {
+            // a few codes per list, any engineered code size but 16 bytes (the multi-index drivers ship 8): no table per probe,
+            // each lane fetches the entries its code addresses (scanm_short.hip)
+            StageTimer tm(h, 2);
+            vlq::launch_scanm_short(a, h->stream);
+            tm.stop();
+            snprintf(h->last_scan, sizeof(h->last_scan), "scanm_short_kernel<%d>", h->M);
+            h->last_walk_first = -1; h->last_walk_limit = 0; h->last_walk_samples = 0; h->last_walk_counts = false;
         } else {
             StageTimer tm(h, 2);
             vlq::launch_scan(a, h->stream);

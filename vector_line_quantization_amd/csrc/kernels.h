@@ -201,6 +201,9 @@ void launch_max_abs(const float* x, int64_t n, unsigned int* out, hipStream_t s)
 void launch_scan16_bigk(const ScanArgs& a, hipStream_t s);
 // same shape, indexes with a few codes per list (multi-index): no per-probe LUT (scan16.hip)
 void launch_scan16_short(const ScanArgs& a, hipStream_t s);
+// the same organisation for the other code sizes (4 ... 64 bytes in the steps scanm.hip serves; per-query table in a.qtab)
+bool scanm_short_supports(const ScanArgs& a);
+void launch_scanm_short(const ScanArgs& a, hipStream_t s);
 // counting sort of query ids by nearest coarse centroid: hist [nlist+1] ints scratch
 // ints of scratch launch_query_order needs in `hist`: 2 x this
 inline size_t query_order_bins_padded(int nlist) {
