@@ -301,6 +301,10 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
     if (h->coarse_screen && h->screen_cnt_host && h->screen_rows_copied >= 1024 &&
         (uint64_t)*h->screen_cnt_host * 200 > h->screen_rows_copied)
         h->coarse_screen = 0;                     // this index's data defeat the screen's bound: matrix path from here on
+    // the radix select + one sort of imi_wide.hip against the running wave selection of kernels.hip (which stops at 1024):
+    // coarse stage of 10 000 queries on 2 x 14 bits at 256 / 512 / 1024 cells 2.09 / 4.93 / 10.5 ms with the wave selection,
+    // 2.73 / 4.22 / 8.69 with the radix select
+    static const int radix_from = [] { const char* e = getenv("VLQ_IMI_RADIX_FROM"); return e ? atoi(e) : 400; }();
     int64_t screened_rows = 0;       // rows that went through the two-pass screen (either half), counted once behind the join
     for (int m = 0; m < 2; m++) {
         const float* cent = h->imi_cent.as<float>() + (size_t)m * kc * dc;
@@ -402,7 +406,7 @@ int imi_page(vlq_ivfpq_t h, int64_t n, const float* x_dev, int k, float* cdis_de
                                          argmin ? nullptr : tab[m], n, kc, dc, h->stream, tmin, argmin ? 0 : n_pad);
         }
         if (argmin) vlq::launch_coarse_argmin(tmin, n, kc, sv[m], si[m], h->stream);
-        else if (T > 1024) vlq::launch_row_select_sorted(tab[m], n, kc, kc, T, sv[m], si[m], h->stream);   // (imi_wide.hip; checked by the caller)
+        else if (T >= radix_from && vlq::row_select_sorted_ok(kc, T)) vlq::launch_row_select_sorted(tab[m], n, kc, kc, T, sv[m], si[m], h->stream);   // (imi_wide.hip)
         else vlq::launch_coarse_select(tab[m], n, kc, T, sv[m], si[m], h->stream, tmin);
     }
     if (screened_rows > 0) TRY(screen_counters_copy(h, screened_rows));      // (both chains have joined the index's stream)
