@@ -9,7 +9,8 @@
 // query (from the per-query table the generic path already computes: any sub-vector width), each wave walks its own probes
 // (no workgroup barrier in the loop), and a lane fetches exactly the M entries of term 2 its code addresses and forms the SAME
 // table entries term2 + (-2 <q, cent>) (fvec_madd, IndexIVFPQ.cpp:641-644) before the left-to-right sum: identical arithmetic,
-// identical results (tests/test_gpu_code_sizes.py: sparse cases against the oracle and against the generic kernel).
+// identical results (tests/test_gpu_imi_wide.py::test_sparse_lists_of_the_other_code_sizes: eight shapes incl. a flat quantizer,
+// store_pairs and ncode, against the oracle bit for bit; the reference drivers' runs: tests/test_reference_drivers.py).
 // Multi-index cells are walked in (first half, second half) order like the 16-byte kernel's (profiles/r06_scan16_short_pmc.txt).
 #include "scan16_common.cuh"
 #include "scan_common.cuh"
