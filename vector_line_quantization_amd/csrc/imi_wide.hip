@@ -15,9 +15,9 @@
 //                              skipped), so k = 2048 is 16 KB: ten queries per CU.  The walk is one chain of dependent steps,
 //                              and a single wave issues an instruction every four cycles at best, so the wave's lanes do a
 //                              sift's comparisons side by side: a sift-down reads five levels of descendants in one LDS
-//                              round trip (62 lanes, one entry each), every pair picks its smaller child at once, the picks
-//                              are followed from the node down by five ballots, and the entries on the path move up in one
-//                              write; a push reads all ancestors of the new slot at once and moves the ones the new value
+//                              round trip (62 lanes, one entry each), every pair picks its smaller child at once, a lane is on
+//                              the path when all its ancestors in the fan were picked (two ballots), and the entries on the
+//                              path move up in one write; a push reads all ancestors of the new slot at once and moves the ones the new value
 //                              beats.  Same comparisons on the same heap positions as Heap.h:89-127 with CMin => the same
 //                              pops in the same order, ties and twice-emitted cells included.  The output holds TERMS during
 //                              the walk and is turned into keys by all 64 lanes behind a barrier; a cell's four table
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64) void imi_minsum_wide_kernel(const float* __rest
     const int L = 31 - __clz(fan_t);
     const int fp = fan_t - (1 << L);
     const bool fan = L <= 5;
-    const int parent_lane = L >= 2 ? (1 << (L - 1)) - 2 + (fp >> 1) : 0;
+    // the lanes of this lane's ancestors inside the fan, and itself: it lies on the sift's path iff all of them were picked
+    u64 anc = fan ? (1ull << lane) : ~0ull;
+    for (int l = L - 1, pp = fp >> 1; fan && l >= 1; l--, pp >>= 1) anc |= 1ull << ((1 << l) - 2 + pp);
     const bool even = (lane & 1) == 0;
     u64 top = 0;                                        // heap[1], carried in registers
 
@@ -250,12 +252,8 @@ __global__ __launch_bounds__(64) void imi_minsum_wide_kernel(const float* __rest
             // first child of the pair picked: its sibling is slot n + 1, or it is the smaller one
             const bool first = even ? (slot + 1 > n || v < vs) : (slot > n || vs < v);
             const bool chosen = valid && (even == first);
-            u64 on = 0;
-#pragma unroll
-            for (int l = 1; l <= 5; l++) {
-                const bool par_on = l == 1 || ((on >> parent_lane) & 1ull);
-                on |= __ballot(L == l && chosen && par_on);
-            }
+            const u64 picked = __ballot(chosen);
+            const u64 on = __ballot((picked & anc) == anc);
             const u64 stop = __ballot(val < v) & on;
             const u64 mv = stop ? (on & ((stop & (0ull - stop)) - 1ull)) : on;
             if ((mv >> lane) & 1ull) heap[slot >> 1] = e;
