@@ -1639,9 +1639,8 @@ __global__ __launch_bounds__(NTH) void imi_minsum_lds_kernel(
 //         follows the picks while the last entry does not win; the nodes walked take their picked child's entry, the end of the
 //         walk the last one.
 // Same comparisons on the same values in the same heap positions => the same pops in the same order, ties included.
-// Measured (10 000 queries, 2 x 14 bits, nprobe 64): 209 -> 168 us.  It is bound by instruction issue now (~160 wave
-// instructions per emitted cell x 63 cells x 10 000 waves on 1024 SIMDs; trimming the shuffles' address arithmetic and the
-// per-cell key arithmetic did not move it: the scalar walk of the pop, ~10 instructions per heap level, is the bulk).
+// Measured (10 000 queries, 2 x 14 bits, nprobe 64): 209 -> 168 us with a scalar walk in the pop (~10 instructions per heap
+// level), 129 us since round 6 (the path by ballots, below).  Bound by instruction issue (~120 wave instructions per emitted cell).
 // Size: two entries after the first cell, at most one more per emitted cell => at most kk + 1 before the pops of iteration kk
 // and kk + 2 after its pushes; the pushes of the last iteration feed nothing and are skipped, so <= 64 for k <= 64.
 template <int NW>
@@ -1684,23 +1683,31 @@ __global__ __launch_bounds__(64 * NW) void imi_minsum_wave_kernel(
             hid = topmost ? id : pid;
         }
     };
+    // (round 6) the walk from the root without a loop: a node is on the sift's path when it and all its ancestors below the root
+    // are their parents' picks -- one ballot of "picked by my parent" against a per-lane CONSTANT mask of those ancestors --, the
+    // walk ends at the first node of the path (lanes are in level order) that has no child or whose picked child beats the last
+    // entry.  168 -> 129 us per 10 000 queries at 64 cells (the scalar walk: ~10 instructions per heap level with a readlane
+    // and a branch each; round 5 built the ancestors' bits with six 64-bit shifts per pop: 177 us).
+    u64 anc = 0;                                        // bits of this node and of its ancestors, the root excluded
+    for (int a = pos; a >= 2; a >>= 1) anc |= 1ull << (a - 1);
+    const int a_parent = ((pos >> 1) - 1) * 4;
     auto pop = [&]() __attribute__((always_inline)) {
         const float lastv = rlf(hv, n - 1);
         const int lastid = rli(hid, n - 1);
         const float cv1 = perm_f(a_c1, hv), cv2 = perm_f(a_c2, hv);
         const int ci1 = __builtin_amdgcn_ds_bpermute(a_c1, hid), ci2 = __builtin_amdgcn_ds_bpermute(a_c2, hid);
         const bool pick1 = (2 * pos + 1 == n + 1) || (cv1 < cv2);
-        const int cc = pick1 ? 2 * pos : 2 * pos + 1;
         const float ccv = pick1 ? cv1 : cv2;
         const int ccid = pick1 ? ci1 : ci2;
-        int cur = 1;
-        u64 walked = 0;
-        while (2 * cur <= n) {
-            const float v = rlf(ccv, cur - 1);
-            if (lastv < v) break;
-            walked |= 1ull << (cur - 1);
-            cur = rli(cc, cur - 1);
-        }
+        // am I my parent's pick?  (left children sit at even positions)
+        const int ppick1 = __builtin_amdgcn_ds_bpermute(a_parent, pick1 ? 1 : 0);
+        const bool mine = pos == 1 || ((pos & 1) == 0) == (ppick1 != 0);
+        const u64 picked = __ballot(mine && pos <= n);
+        const u64 on = __ballot((picked & anc) == anc && pos <= n);
+        // the walk stops at a node without children, or whose picked child the last entry beats
+        const u64 stop = __ballot(2 * pos > n || lastv < ccv) & on;
+        const int cur = __builtin_ctzll(stop) + 1;          // (a path always ends: its deepest node has no child)
+        const u64 walked = on & ((1ull << (cur - 1)) - 1ull);
         if ((walked >> lane) & 1ull) { hv = ccv; hid = ccid; }
         if (lane == cur - 1) { hv = lastv; hid = lastid; }
         n--;
