@@ -31,7 +31,11 @@ def make(nlist, d, rng, offset=0.0, spread=1.0):
                                                     (8192, 32, 64, None), (1024, 32, 64, True), (4096, 64, 128, None), (1024, 32, 100, None),
                                                     # rows wider than 8192 columns: tile minima from the distance kernel, tiled keep kernel
                                                     (16384, 64, 32, None), (65536, 16, 8, None), (131072, 8, 16, None), (16448, 32, 64, None),
-                                                    (131072, 16, 128, None), (8256, 32, 128, None)])
+                                                    (131072, 16, 128, None), (8256, 32, 128, None),
+                                                    # round 6: the matrix-free passes beyond 16 384 lists (several ranges per workgroup,
+                                                    # the last one ragged) and beyond 64 probes (the bound by bisection, two result registers)
+                                                    (32768, 96, 100, None), (65536, 64, 64, None), (131072, 32, 40, None), (20032, 32, 65, None),
+                                                    (16384, 48, 128, None)])
 def test_screened_coarse_equals_oracle(nlist, d, nprobe, decides):
     rng = np.random.default_rng(nlist + d + nprobe)
     g, ox, cent = make(nlist, d, rng)
@@ -104,7 +108,7 @@ def test_queries_outside_the_half_range_and_nan_rows():
     assert np.array_equal(bits(cd1), bits(cd0)) and np.array_equal(keys1, keys0)
 
 
-@pytest.mark.parametrize("nlist,d,nprobe", [(1024, 32, 8), (4096, 128, 32), (16384, 64, 32)])
+@pytest.mark.parametrize("nlist,d,nprobe", [(1024, 32, 8), (4096, 128, 32), (16384, 64, 32), (131072, 16, 100)])
 @pytest.mark.parametrize("far", [1.5, 2.0, 3.0, 4.0, 8.0])
 def test_outlier_queries_near_the_half_overflow(nlist, d, nprobe, far):
     """Queries at 1.5 ... 8 times the centroid cloud's radius from its centre: their stored half distances reach the top

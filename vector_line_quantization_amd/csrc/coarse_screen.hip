@@ -177,7 +177,7 @@ template <int KS, int PASS>
 __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float16* __restrict__ Qh, const _Float16* __restrict__ Ch,
                                                                    const float* __restrict__ cn, int64_t nq, int nlist, int nb_range,
                                                                    float m2_inv_s2, float* __restrict__ pool, int npool,
-                                                                   const float* __restrict__ tsub, uint32_t* __restrict__ bits) {
+                                                                   const float* __restrict__ tsub, uint32_t* __restrict__ bits, int nsub) {
     // The centroid blocks reach the four waves through LDS: stages of SB blocks in a ring of RING buffers, filled by LDS-DMA
     // (global_load_lds_dwordx4: a wave instruction moves 1 KB, no registers) three stages ahead -- every wave issues a quarter
     // of a stage (a linear copy: the operand order keeps a stage's blocks contiguous), waits for its own share of the stage
@@ -202,23 +202,11 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
     const int n = lane & 31, h = lane >> 5;
     const int64_t nrb = (nq + 127) / 128 * 4;                     // query blocks of 32 the half copy holds (zero rows past nq)
     const int64_t rb0 = ((int64_t)blockIdx.x * 4 + wave) * QW;    // this wave's first query block
-    const int range = blockIdx.y;
-    const int cb0 = range * nb_range;                             // first centroid block of 32
+    // (round 6) a workgroup takes nsub consecutive ranges one after the other -- indexes of more than 16 384 lists: the bound's
+    // pool stays at <= 1024 class minima per row (class m = centroid mod 32 of every SUPER-range of nsub ranges), pass 0's running
+    // minima simply run on over the sub-ranges, pass 1 leaves its bits range by range
+    const int srange = blockIdx.y;
     const int nblk = nlist >> 5;
-    const int nb = min(nb_range, nblk - cb0);                     // >= 1 by the launch's grid; even (nlist % 64 == 0, nb_range even)
-    const h16x8* cbase = reinterpret_cast<const h16x8*>(Ch) + (int64_t)cb0 * (KS * 64);
-    const int nel = nb * KS * 64;                                 // 16-byte elements of the range
-    // every stage is PT instructions per wave, past the range's end too (the last element again, into a buffer nobody reads):
-    // the count in flight at a wait is then a constant
-    auto stage_issue = [&](int st) __attribute__((always_inline)) {
-        const int buf = st % RING;
-#pragma unroll
-        for (int i = 0; i < PT; i++) {
-            const int e = min(st * STAGE + i * 256 + (int)threadIdx.x, nel - 1);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(cbase + e),
-                                             (void __attribute__((address_space(3)))*)(&cl[buf][i * 256 + wave * 64]), 16, 0, 0);
-        }
-    };
     // set-up loads first (older than every stage: a wait for them never waits for a stage)
     h16x8 qf[QW][KS];
 #pragma unroll
@@ -237,6 +225,29 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
             tvu[qb] = __uint_as_float(f32_to_ordered_inv(f32_to_ordered(tv) + 1u));
         }
     }
+    float mn[QW][16];
+#pragma unroll
+    for (int qb = 0; qb < QW; qb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mn[qb][r] = FLT_MAX_F;
+    for (int sr = 0; sr < nsub; sr++) {
+    const int range = srange * nsub + sr;
+    const int cb0 = range * nb_range;                             // first centroid block of 32
+    if (cb0 >= nblk) break;                                       // (workgroup-uniform)
+    const int nb = min(nb_range, nblk - cb0);                     // >= 1; even (nlist % 64 == 0, nb_range even)
+    const h16x8* cbase = reinterpret_cast<const h16x8*>(Ch) + (int64_t)cb0 * (KS * 64);
+    const int nel = nb * KS * 64;                                 // 16-byte elements of the range
+    // every stage is PT instructions per wave, past the range's end too (the last element again, into a buffer nobody reads):
+    // the count in flight at a wait is then a constant
+    auto stage_issue = [&](int st) __attribute__((always_inline)) {
+        const int buf = st % RING;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const int e = min(st * STAGE + i * 256 + (int)threadIdx.x, nel - 1);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(cbase + e),
+                                             (void __attribute__((address_space(3)))*)(&cl[buf][i * 256 + wave * 64]), 16, 0, 0);
+        }
+    };
     float cnr[(NBR * 32 + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnr[i] = cn[(int64_t)cb0 * 32 + min(i * 256 + (int)threadIdx.x, nb * 32 - 1)];
@@ -244,11 +255,6 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
     stage_issue(1);
 #pragma unroll
     for (int i = 0; i < (NBR * 32 + 255) / 256; i++) cnl[i * 256 + threadIdx.x] = cnr[i];
-    float mn[QW][16];
-#pragma unroll
-    for (int qb = 0; qb < QW; qb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mn[qb][r] = FLT_MAX_F;
     const int nst = nb / SB;
     for (int st = 0; st < nst; st++) {
         const int buf = st % RING;
@@ -309,19 +315,27 @@ __global__ __launch_bounds__(256, 2) void coarse_f16_stream_kernel(const _Float1
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): the repeats issued past the range's end
     __syncthreads();
+    if (PASS == 1) {
 #pragma unroll
-    for (int qb = 0; qb < QW; qb++) {
-        const int64_t row = (rb0 + qb) * 32 + n;
-        if (row >= nq) continue;
-        if (PASS == 1) {
+        for (int qb = 0; qb < QW; qb++) {
+            const int64_t row = (rb0 + qb) * 32 + n;
+            if (row >= nq) continue;
             // the range's words of 32 queries: out as contiguous bytes per query
             const int nw = nlist >> 5;
             uint32_t* dst = bits + row * nw + cb0 + (NBR / 2) * h;
 #pragma unroll
             for (int j = 0; j < NBR / 2; j++)
                 if ((NBR / 2) * h + j < nb) dst[j] = wt[wave * QW + qb][n][(NBR / 2) * h + j];
-        } else {
-            float* dst = pool + row * npool + range * 32 + 4 * h;     // class m = 8 g + 4 h + i of this range
+        }
+    }
+    if (sr + 1 < nsub) __syncthreads();           // the next sub-range refills the norms, the ring and the word table
+    }   // sub-ranges
+    if (PASS == 0) {
+#pragma unroll
+        for (int qb = 0; qb < QW; qb++) {
+            const int64_t row = (rb0 + qb) * 32 + n;
+            if (row >= nq) continue;
+            float* dst = pool + row * npool + srange * 32 + 4 * h;    // class m = 8 g + 4 h + i of this super-range
 #pragma unroll
             for (int g = 0; g < 4; g++)
                 *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(mn[qb][4 * g], mn[qb][4 * g + 1], mn[qb][4 * g + 2], mn[qb][4 * g + 3]);
@@ -691,7 +705,25 @@ __global__ __launch_bounds__(256) void coarse_screen_cut_kernel(const float* __r
         return v;
     };
     if (MT >= 2) sk[0] = lo64(sk[0], sk[SK - 1]);
-    const float cutv = ordered_to_f32((uint32_t)__builtin_amdgcn_readlane((int)sk[0], nprobe - 1));
+    float cutv = ordered_to_f32((uint32_t)__builtin_amdgcn_readlane((int)sk[0], min(nprobe, 64) - 1));
+    if (nprobe > 64) {
+        // (round 6: 64 < nprobe <= 128) the nprobe-th smallest of ALL the pool's values, exactly: bisection on the ordered image --
+        // the smallest K with at least nprobe values <= K (32 steps of MT compares per lane and one count over the wave)
+        uint32_t lo = 0u, hi = 0xFFFFFFFFu;
+        uint32_t om[MT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) om[i] = f32_to_ordered(mt[i]);
+        for (int it = 0; it < 32; it++) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < MT; i++) c += om[i] <= mid ? 1 : 0;
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) c += (int)lane_xor_u32((uint32_t)c, sft);
+            if (c >= nprobe) hi = mid; else lo = mid + 1u;
+        }
+        cutv = ordered_to_f32(lo);
+    }
     const float qc = qn[q];
     const float cut = __fadd_rn(qc, cutv);                        // ... of the approximate distances a = qn_c + v' (monotone)
     bool finite;
@@ -957,10 +989,21 @@ size_t coarse_screen_keep_bytes(int64_t nq, int nlist) {
     const size_t free_ = (size_t)nq * ((size_t)(nlist >> 5) * 4 + 4 + 1) + 64;
     return std::max(lists, free_);
 }
-// the matrix-free form serves 64 <= nlist / 64 tiles <= 256 per row (the bound's pool) and nprobe <= 64
+// the matrix-free form: a pool of 32 class minima per (super-)range of 512 x nsub columns, at most 1024 per row, at least
+// 2 nprobe of them; round 5: up to 16 384 lists and 64 probes; round 6: up to 2^20 lists (nsub ranges per workgroup) and 128 probes
+// (VLQ_COARSE_MATRIX_FREE_WIDE=0: round 5's limits, the half-matrix form beyond them)
+static int matrix_free_nsub(int nlist) {
+    const int nranges = ((nlist >> 5) + 15) / 16;
+    return (nranges + 31) / 32;
+}
 bool coarse_screen_matrix_free_ok(int nlist, int nprobe) {
     static const bool off = getenv("VLQ_COARSE_MATRIX") != nullptr;      // A/B: the half matrix of rounds 3-4
-    return !off && nlist >= 1024 && nlist <= 16384 && nprobe <= 64 && nprobe * 2 <= 32 * (((nlist >> 5) + 15) / 16);
+    static const bool wide = !(getenv("VLQ_COARSE_MATRIX_FREE_WIDE") && atoi(getenv("VLQ_COARSE_MATRIX_FREE_WIDE")) == 0);
+    if (off || nlist < 1024 || (nlist & 63)) return false;
+    if (!wide && (nlist > 16384 || nprobe > 64)) return false;
+    const int nranges = ((nlist >> 5) + 15) / 16;
+    const int nsuper = (nranges + matrix_free_nsub(nlist) - 1) / matrix_free_nsub(nlist);
+    return nlist <= (1 << 20) && nprobe <= 128 && nprobe * 2 <= 32 * nsuper;
 }
 
 void launch_coarse_screened(const float* q, const void* q_half, const unsigned char* q_flags, const float* c, const void* c_half,
@@ -995,14 +1038,16 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
         // a range = 16 blocks of 32 centroids (512 columns); the bound's pool = 32 classes per range
         const int nb_range = 16;
         const int nranges = ((nlist >> 5) + nb_range - 1) / nb_range;
-        const int npool = 32 * nranges;
-        float* pool = tmin_ws;                                     // [nq][npool]  (npool <= nlist / 64 * 2: the caller sized it for nlist / 64 floats ... x 2 below)
-        dim3 sgridq((unsigned)((nq + 255) / 256), (unsigned)nranges);      // a workgroup = 4 waves x 64 queries
+        const int nsub = matrix_free_nsub(nlist);                   // ranges per workgroup (1 up to 16 384 lists)
+        const int nsuper = (nranges + nsub - 1) / nsub;
+        const int npool = 32 * nsuper;                             // <= 1024
+        float* pool = tmin_ws;                                     // [nq][npool]  (the caller sized it for nlist / 16 + 32 floats per row)
+        dim3 sgridq((unsigned)((nq + 255) / 256), (unsigned)nsuper);       // a workgroup = 4 waves x 64 queries
         const float m2 = -2.f * inv_s2;
 #define VLQ_STR0(K) hipLaunchKernelGGL((coarse_f16_stream_kernel<K, 0>), sgridq, dim3(256), 0, s, qh, ch, cn_c, nq, nlist, nb_range, m2, pool, npool, \
-                                       (const float*)nullptr, (uint32_t*)nullptr)
+                                       (const float*)nullptr, (uint32_t*)nullptr, nsub)
 #define VLQ_STR1(K) hipLaunchKernelGGL((coarse_f16_stream_kernel<K, 1>), sgridq, dim3(256), 0, s, qh, ch, cn_c, nq, nlist, nb_range, m2, (float*)nullptr, npool, \
-                                       (const float*)trow, bits)
+                                       (const float*)trow, bits, nsub)
 #define VLQ_KS(M) switch (ks) { case 1: M(1); break; case 2: M(2); break; case 3: M(3); break; case 4: M(4); break; case 5: M(5); break; \
                                 case 6: M(6); break; case 7: M(7); break; default: M(8); break; }
         VLQ_KS(VLQ_STR0)
@@ -1011,8 +1056,12 @@ void launch_coarse_screened(const float* q, const void* q_half, const unsigned c
                                        c_sub, trow, rflag)
         if (npool <= 64) VLQ_CUT(1); else if (npool <= 128) VLQ_CUT(2); else if (npool <= 256) VLQ_CUT(4); else if (npool <= 512) VLQ_CUT(8); else VLQ_CUT(16);
         VLQ_KS(VLQ_STR1)
-        hipLaunchKernelGGL((coarse_screen_exact_kernel<1, true>), sgrid, block, 0, s, (const uint32_t*)nullptr, (const uint16_t*)nullptr, nq, nlist,
-                           nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows, oh);
+        if (nprobe <= 64)
+            hipLaunchKernelGGL((coarse_screen_exact_kernel<1, true>), sgrid, block, 0, s, (const uint32_t*)nullptr, (const uint16_t*)nullptr, nq, nlist,
+                               nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows, oh);
+        else
+            hipLaunchKernelGGL((coarse_screen_exact_kernel<2, true>), sgrid, block, 0, s, (const uint32_t*)nullptr, (const uint16_t*)nullptr, nq, nlist,
+                               nprobe, cdis, keys, q, c, qn, cn, d, kept_total, (const uint32_t*)bits, (const unsigned char*)rflag, exact_rows, oh);
         if (hist_done) *hist_done = oh.hist != nullptr;
 #undef VLQ_STR0
 #undef VLQ_STR1
